@@ -1,0 +1,238 @@
+/*
+ * slam_amd.h -- C ABI of the MI355X (gfx950) ORB frontend: pyramid, FAST-9/16,
+ * per-level best-N selection, intensity-centroid orientation, rBRIEF descriptors
+ * and gated brute-force Hamming matching, as hand-written HIP kernels.
+ *
+ * This is the boundary a maintainer of pxl-th/slam binds to in place of the two
+ * OpenCV calls that carry the reference's frontend arithmetic:
+ *   cv::ORB::detectAndCompute      (reference: src/frame/detector.cpp:11)
+ *   cv::BFMatcher::radiusMatch     (reference: src/frame/matcher.cpp:43-45, 111-113)
+ * plus the post-filter and projection around them (src/frame/matcher.cpp:131-184).
+ * The C++ classes that keep the reference's slam::Detector / slam::Matcher
+ * signatures on top of this ABI are in slam_amd.hpp.
+ *
+ * Conventions: every function returns an int status (0 = ok, negative = error),
+ * never throws, never takes ownership of caller memory.  Record layouts equal
+ * cv::KeyPoint (28 bytes) and cv::DMatch (16 bytes).  "Host" entry points take
+ * host pointers and block until results are on the host, as the reference's
+ * callers expect (src/tracking/tracker.cpp:74-75).  "_async" entry points take
+ * device pointers and a hipStream_t (passed as void*), enqueue work and return.
+ * One context serves one host thread at a time.  There is no CPU fallback: with
+ * no usable GPU the create calls fail with SLAM_AMD_ERR_NO_DEVICE.
+ *
+ * Keypoint order is canonical: (octave, y, x) ascending.  Match ties (equal
+ * Hamming distance) resolve to the lowest train index.
+ */
+#ifndef SLAM_AMD_H
+#define SLAM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM_AMD_MAX_LEVELS 16
+#define SLAM_AMD_VERSION 100
+
+enum {
+    SLAM_AMD_OK = 0,
+    SLAM_AMD_ERR_ARG = -1,         /* null pointer, bad size, bad parameter value */
+    SLAM_AMD_ERR_UNSUPPORTED = -2, /* ORB variant not implemented (Harris score, WTA_K != 2, ...) */
+    SLAM_AMD_ERR_CAPACITY = -3,    /* more results than the caller's buffer holds; *n_out = needed */
+    SLAM_AMD_ERR_NOMEM = -4,
+    SLAM_AMD_ERR_HIP = -5,         /* a HIP runtime call failed; see slam_amd_last_error() */
+    SLAM_AMD_ERR_NO_DEVICE = -6    /* no gfx950-compatible GPU visible */
+};
+
+/* Same 28-byte layout as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id). */
+typedef struct {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} slam_amd_keypoint;
+
+/* Same 16-byte layout as cv::DMatch (queryIdx, trainIdx, imgIdx, distance). */
+typedef struct {
+    int32_t queryIdx, trainIdx, imgIdx;
+    float distance;
+} slam_amd_dmatch;
+
+/* Arguments of cv::ORB::create as the reference passes them (main.cpp:100:
+ * 1000, 1.2f, 8, 31, 0, 2, FAST_SCORE) plus patchSize and fastThreshold. */
+typedef struct {
+    int32_t nfeatures;
+    float   scale_factor;
+    int32_t nlevels;        /* 1..SLAM_AMD_MAX_LEVELS */
+    int32_t edge_threshold; /* >= 31 */
+    int32_t first_level;    /* must be 0 */
+    int32_t wta_k;          /* must be 2 */
+    int32_t score_type;     /* must be 1 (cv::ORB::FAST_SCORE) */
+    int32_t patch_size;     /* must be 31 */
+    int32_t fast_threshold; /* 0..255, OpenCV default 20 */
+} slam_amd_orb_params;
+
+typedef struct slam_amd_extractor slam_amd_extractor;
+typedef struct slam_amd_matcher slam_amd_matcher;
+
+/* ---- general ---------------------------------------------------------- */
+
+int slam_amd_version(void);
+const char* slam_amd_status_string(int status);
+/* Message of the last failing call on this thread ("" if none). */
+const char* slam_amd_last_error(void);
+int slam_amd_device_count(int* count);
+/* Fills the parameters of main.cpp:100 (nfeatures 1000, 1.2, 8 levels, ...). */
+void slam_amd_default_orb_params(slam_amd_orb_params* p);
+
+/* ---- extraction: replaces cv::ORB::detectAndCompute ---------------------
+ * reference: slam::Detector::detect, src/frame/detector.cpp:6-12 */
+
+/* A context is bound to one image size, one device, a maximum batch of frames
+ * per call and a maximum number of keypoints per frame. */
+int slam_amd_extractor_create(const slam_amd_orb_params* params, int width, int height,
+                              int max_batch, int max_keypoints, int device,
+                              slam_amd_extractor** out);
+int slam_amd_extractor_destroy(slam_amd_extractor* ex);
+
+/* Pyramid geometry: any output pointer may be null.  Arrays hold nlevels entries.
+ * reference: Detector::getLevels / getScaleFactor, include/frame/detector.hpp:35-36 */
+int slam_amd_extractor_levels(const slam_amd_extractor* ex, int* nlevels, int* widths,
+                              int* heights, int* quotas, float* scales);
+
+/* Host, blocking.  gray: 8-bit single channel, `stride` bytes per row.  Writes at
+ * most `capacity` keypoints (28-byte records) and descriptors (row-major N x 32).
+ * An image of the wrong size is SLAM_AMD_ERR_ARG.  More keypoints than capacity
+ * (score ties can exceed nfeatures, include/frame/detector.hpp:25-27) is
+ * SLAM_AMD_ERR_CAPACITY with *n_out = the number needed and nothing written. */
+int slam_amd_extract(slam_amd_extractor* ex, const uint8_t* gray, int width, int height,
+                     int stride, slam_amd_keypoint* kp_out, uint8_t* desc_out,
+                     int capacity, int* n_out);
+
+/* Device, asynchronous, batched.  d_images: `batch` frames, frame b starts at
+ * d_images + b*frame_pitch, rows `row_stride` bytes apart.  Outputs are
+ * [batch][capacity] keypoints, [batch][capacity][32] descriptor bytes and
+ * [batch] counts.  d_count[b] is the true number found; when it exceeds
+ * `capacity` only the first `capacity` (canonical order) are written. */
+int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_t* d_images, int batch,
+                                 size_t frame_pitch, int row_stride,
+                                 slam_amd_keypoint* d_kp, uint8_t* d_desc, int32_t* d_count,
+                                 int capacity, void* stream);
+
+/* Device copy of the unblurred pyramid of frame b of the last batch (level l has
+ * widths[l] columns; `pitch` receives its row pitch in bytes).  For tests. */
+int slam_amd_extractor_debug_level(slam_amd_extractor* ex, int frame, int level,
+                                   uint8_t* host_out, int host_stride);
+
+/* ---- matching: replaces cv::BFMatcher::radiusMatch + _filterMatches ------
+ * reference: slam::Matcher::frameMatch, src/frame/matcher.cpp:15-55 and
+ * Matcher::_filterMatches, src/frame/matcher.cpp:131-161 */
+
+int slam_amd_matcher_create(int device, slam_amd_matcher** out);
+int slam_amd_matcher_destroy(slam_amd_matcher* m);
+/* Sizes the matcher's device scratch (4 bytes per query row over all problems
+ * of a call) so that later _async calls of at most that size allocate nothing. */
+int slam_amd_matcher_reserve(slam_amd_matcher* m, size_t query_rows);
+
+/* Host, blocking.  For every query row (ascending), the train row of least
+ * Hamming distance among those that pass the gates:
+ *   distance <= max_dist                                   (matcher.cpp:43-45)
+ *   not (max_level != -1 && q.octave > max_level && t.octave > max_level)
+ *                                                           (matcher.cpp:144-148)
+ *   area == -1 || (|q.x - t.x| < area && |q.y - t.y| < area) (matcher.cpp:149-157)
+ * ids (may be null / n_ids 0): rows of set 1 to use as queries, in that order;
+ * queryIdx of the result is the id (matcher.cpp:26-36, 51-53).
+ * q_xy (may be null): 2 floats per query replacing the query positions in the
+ * window gate (projectionMatch, matcher.cpp:114-120).
+ * out holds at most one record per query; *n_out = number of matches. */
+int slam_amd_frame_match(slam_amd_matcher* m,
+                         const uint8_t* desc1, const slam_amd_keypoint* kp1, int n1,
+                         const uint8_t* desc2, const slam_amd_keypoint* kp2, int n2,
+                         const int32_t* ids, int n_ids, const float* q_xy,
+                         float max_dist, float area, int max_level,
+                         slam_amd_dmatch* out, int* n_out);
+
+/* Device, asynchronous.  Same semantics on device arrays.  d_n1 / d_n2 (may be
+ * null) point to device int32 counts that override n1 / n2 when smaller, so the
+ * call can be chained behind slam_amd_extract_batch_async without a host sync.
+ * d_out: [max queries] cv::DMatch records, d_n_out: device int32 match count.
+ * d_ids and d_q_xy as in the host call (device pointers, may be null). */
+int slam_amd_frame_match_async(slam_amd_matcher* m,
+                               const uint8_t* d_desc1, const slam_amd_keypoint* d_kp1, int n1,
+                               const int32_t* d_n1,
+                               const uint8_t* d_desc2, const slam_amd_keypoint* d_kp2, int n2,
+                               const int32_t* d_n2,
+                               const int32_t* d_ids, int n_ids, const float* d_q_xy,
+                               float max_dist, float area, int max_level,
+                               slam_amd_dmatch* d_out, int32_t* d_n_out, void* stream);
+
+/* Batched matching of `batch` independent (set 1, set 2) problems of equal
+ * capacity in one launch: problem b uses rows [b*cap1, b*cap1+n1[b]) of set 1
+ * and [b*cap2, b*cap2+n2[b]) of set 2 (counts on the device).  Output
+ * d_out[b*cap1 + i], d_n_out[b].  Serves frame-vs-previous-frame matching of a
+ * batch of frames. */
+int slam_amd_frame_match_batch_async(slam_amd_matcher* m, int batch,
+                                     const uint8_t* d_desc1, const slam_amd_keypoint* d_kp1,
+                                     int cap1, const int32_t* d_n1,
+                                     const uint8_t* d_desc2, const slam_amd_keypoint* d_kp2,
+                                     int cap2, const int32_t* d_n2,
+                                     float max_dist, float area, int max_level,
+                                     slam_amd_dmatch* d_out, int32_t* d_n_out, void* stream);
+
+/* Keyframe-pair batch: n_keyframes descriptor sets of n_per rows each, resident
+ * on the device ([n_keyframes][n_per][32]; d_kp [n_keyframes][n_per] may be null
+ * when both gates are off).  d_pairs: n_pairs (query keyframe, train keyframe)
+ * index pairs.  Output: one 32-bit word per query row of every pair,
+ * (distance << 16) | trainIdx, or 0xFFFFFFFF when no train row passes.
+ * n_per <= 65535.  This is frameMatch(kf_i, kf_j, {}, ...) for many pairs, the
+ * all-defaults form of src/tracking/mapper.cpp:34. */
+int slam_amd_match_pairs_async(slam_amd_matcher* m,
+                               const uint8_t* d_desc, const slam_amd_keypoint* d_kp,
+                               int n_keyframes, int n_per,
+                               const int32_t* d_pairs, int n_pairs,
+                               float max_dist, float area, int max_level,
+                               uint32_t* d_out, void* stream);
+
+/* ---- projection: replaces cv::Rodrigues + cv::projectPoints ----------------
+ * reference: Matcher::_projectMapPoints, src/frame/matcher.cpp:163-184 */
+
+/* Host, blocking.  Rt: row-major 3x4 pose [R|t] of the target keyframe;
+ * K4: fx, fy, cx, cy; dist5: k1 k2 p1 p2 k3 or null; xyz: n world points;
+ * uv: n projected pixels.  Arithmetic in double, results rounded to float. */
+int slam_amd_project_points(slam_amd_matcher* m, const double* Rt, const double* K4,
+                            const double* dist5, const float* xyz, int n, float* uv);
+
+int slam_amd_project_points_async(slam_amd_matcher* m, const double* Rt, const double* K4,
+                                  const double* dist5, const float* d_xyz, int n, float* d_uv,
+                                  void* stream);
+
+/* ---- duplicate map points: replaces the per-pair BFMatcher::match loop -----
+ * reference: Mapper::_isDuplicate / _keyframeDuplicates,
+ * src/tracking/mapper.cpp:292-346 */
+
+/* Host, blocking.  flag[i*n2 + j] = 1 when hamming(desc1[i], desc2[j]) <=
+ * desc_dist and the Euclidean distance of world points pos1[i], pos2[j] (3
+ * floats each) is < point_dist, else 0. */
+int slam_amd_duplicate_pairs(slam_amd_matcher* m,
+                             const uint8_t* desc1, const float* pos1, int n1,
+                             const uint8_t* desc2, const float* pos2, int n2,
+                             int desc_dist, double point_dist, uint8_t* flag);
+
+/* ---- host-side helpers exported for tests --------------------------------- */
+
+/* cos and sin of a float angle (radians, 0 <= a <= 7) computed in double by the
+ * routine the descriptor kernel uses, rounded to float. */
+void slam_amd_sincos_f32(float angle_rad, float* cos_out, float* sin_out);
+/* The degree-7 polynomial atan2 (degrees) the orientation kernel uses. */
+float slam_amd_fast_atan2(float y, float x);
+/* INTER_LINEAR_EXACT tables of one axis as the pyramid kernel receives them. */
+int slam_amd_linear_exact_coeffs(int src_size, int dst_size, int32_t* offsets, uint16_t* c1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,289 @@
+"""ctypes binding of libslam_amd.so (the C ABI in include/slam_amd.h).
+
+Used by the tests and the benchmark to drive the HIP library from Python.  There
+is no fallback: a missing library raises at load time, a missing GPU makes the
+create calls fail with SLAM_AMD_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslam_amd.so")
+
+KEYPOINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]
+)
+DMATCH_DTYPE = np.dtype(
+    [("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")]
+)
+
+OK, ERR_ARG, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_NOMEM, ERR_HIP, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/slam_amd.h declares
+EXPORTS = [
+    "slam_amd_version", "slam_amd_status_string", "slam_amd_last_error", "slam_amd_device_count",
+    "slam_amd_default_orb_params",
+    "slam_amd_extractor_create", "slam_amd_extractor_destroy", "slam_amd_extractor_levels",
+    "slam_amd_extract", "slam_amd_extract_batch_async", "slam_amd_extractor_debug_level",
+    "slam_amd_matcher_create", "slam_amd_matcher_destroy", "slam_amd_matcher_reserve",
+    "slam_amd_frame_match", "slam_amd_frame_match_async", "slam_amd_frame_match_batch_async",
+    "slam_amd_match_pairs_async",
+    "slam_amd_project_points", "slam_amd_project_points_async", "slam_amd_duplicate_pairs",
+    "slam_amd_sincos_f32", "slam_amd_fast_atan2", "slam_amd_linear_exact_coeffs",
+]
+
+
+class OrbParams(C.Structure):
+    _fields_ = [
+        ("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+        ("edge_threshold", C.c_int32), ("first_level", C.c_int32), ("wta_k", C.c_int32),
+        ("score_type", C.c_int32), ("patch_size", C.c_int32), ("fast_threshold", C.c_int32),
+    ]
+
+
+class SlamAmdError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("slam_amd status %d: %s" % (status, message))
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """Load libslam_amd.so; raises OSError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError("%s not found: build it with `make -C slam_amd/csrc` "
+                          "(or __graft_entry__.build())" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        l.slam_amd_status_string.restype = C.c_char_p
+        l.slam_amd_last_error.restype = C.c_char_p
+        l.slam_amd_fast_atan2.restype = C.c_float
+        l.slam_amd_fast_atan2.argtypes = [C.c_float, C.c_float]
+        l.slam_amd_sincos_f32.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        l.slam_amd_sincos_f32.restype = None
+        l.slam_amd_default_orb_params.restype = None
+        l.slam_amd_matcher_reserve.argtypes = [C.c_void_p, C.c_size_t]
+        l.slam_amd_extract_batch_async.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
+            C.c_void_p, C.c_int, C.c_void_p]
+        l.slam_amd_frame_match_async.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+            C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int,
+            C.c_void_p, C.c_void_p, C.c_void_p]
+        l.slam_amd_frame_match_batch_async.argtypes = [
+            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+            C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.slam_amd_match_pairs_async.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+            C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        l.slam_amd_frame_match.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+            C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p,
+            C.POINTER(C.c_int)]
+        l.slam_amd_extract.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+            C.POINTER(C.c_int)]
+        l.slam_amd_extractor_create.argtypes = [
+            C.POINTER(OrbParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        l.slam_amd_extractor_destroy.argtypes = [C.c_void_p]
+        l.slam_amd_extractor_levels.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        l.slam_amd_extractor_debug_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        l.slam_amd_matcher_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        l.slam_amd_matcher_destroy.argtypes = [C.c_void_p]
+        l.slam_amd_project_points.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+        l.slam_amd_project_points_async.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p]
+        l.slam_amd_duplicate_pairs.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+            C.c_int, C.c_double, C.c_void_p]
+        l.slam_amd_linear_exact_coeffs.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _lib = l
+    return _lib
+
+
+def check(status):
+    if status != OK:
+        raise SlamAmdError(status, lib().slam_amd_last_error().decode())
+
+
+def orb_params(nfeatures=1000, scale_factor=1.2, nlevels=8, edge_threshold=31, fast_threshold=20,
+               first_level=0, wta_k=2, score_type=1, patch_size=31):
+    return OrbParams(nfeatures, scale_factor, nlevels, edge_threshold, first_level, wta_k,
+                     score_type, patch_size, fast_threshold)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if hasattr(a, "data_ptr"):  # torch tensor
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(type(a))
+
+
+def sincos_f32(angle_rad):
+    c = C.c_float(); s = C.c_float()
+    lib().slam_amd_sincos_f32(C.c_float(angle_rad), C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
+def fast_atan2(y, x):
+    return float(lib().slam_amd_fast_atan2(float(y), float(x)))
+
+
+def linear_exact_coeffs(src, dst):
+    off = np.zeros(dst, np.int32); c1 = np.zeros(dst, np.uint16)
+    check(lib().slam_amd_linear_exact_coeffs(src, dst, _ptr(off), _ptr(c1)))
+    return off, c1
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().slam_amd_device_count(C.byref(n)))
+    return n.value
+
+
+class Extractor:
+    """Owner of a slam_amd_extractor handle."""
+
+    def __init__(self, params, width, height, max_batch=1, max_keypoints=None, device=0):
+        self.params = params
+        self.width, self.height = width, height
+        self.max_batch = max_batch
+        self.max_keypoints = max_keypoints or max(4 * params.nfeatures, 1024)
+        self.device = device
+        self._h = C.c_void_p()
+        check(lib().slam_amd_extractor_create(C.byref(params), width, height, max_batch,
+                                               self.max_keypoints, device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().slam_amd_extractor_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def levels(self):
+        n = C.c_int(0)
+        ws = np.zeros(16, np.int32); hs = np.zeros(16, np.int32); qs = np.zeros(16, np.int32)
+        sc = np.zeros(16, np.float32)
+        check(lib().slam_amd_extractor_levels(self._h, C.cast(C.byref(n), C.c_void_p), _ptr(ws),
+                                               _ptr(hs), _ptr(qs), _ptr(sc)))
+        k = n.value
+        return ws[:k].copy(), hs[:k].copy(), qs[:k].copy(), sc[:k].copy()
+
+    def extract(self, img, capacity=None):
+        """Host, blocking: numpy image in, (keypoints, descriptors) out."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = capacity if capacity is not None else self.max_keypoints
+        kps = np.zeros(max(cap, 1), KEYPOINT_DTYPE)
+        desc = np.zeros((max(cap, 1), 32), np.uint8)
+        n = C.c_int(0)
+        check(lib().slam_amd_extract(self._h, _ptr(img), w, h, img.strides[0], _ptr(kps), _ptr(desc),
+                                      cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch_async(self, d_images, batch, frame_pitch, row_stride, d_kp, d_desc, d_count,
+                            capacity, stream=0):
+        check(lib().slam_amd_extract_batch_async(self._h, _ptr(d_images), batch, frame_pitch, row_stride,
+                                                  _ptr(d_kp), _ptr(d_desc), _ptr(d_count), capacity,
+                                                  C.c_void_p(stream)))
+
+    def debug_level(self, frame, level):
+        ws, hs, _, _ = self.levels()
+        out = np.zeros((hs[level], ws[level]), np.uint8)
+        check(lib().slam_amd_extractor_debug_level(self._h, frame, level, _ptr(out), int(ws[level])))
+        return out
+
+
+class Matcher:
+    """Owner of a slam_amd_matcher handle."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib().slam_amd_matcher_create(device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().slam_amd_matcher_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reserve(self, rows):
+        check(lib().slam_amd_matcher_reserve(self._h, rows))
+
+    def frame_match(self, d1, kp1, d2, kp2, ids=None, q_xy=None, max_dist=300.0, area=-1.0, max_level=4):
+        """Host, blocking (numpy in, numpy DMatch records out)."""
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        kp1 = None if kp1 is None else np.ascontiguousarray(kp1, KEYPOINT_DTYPE)
+        kp2 = None if kp2 is None else np.ascontiguousarray(kp2, KEYPOINT_DTYPE)
+        ids_a = None if ids is None or len(ids) == 0 else np.ascontiguousarray(ids, np.int32)
+        xy = None if q_xy is None else np.ascontiguousarray(q_xy, np.float32)
+        nq = len(d1) if ids_a is None else len(ids_a)
+        out = np.zeros(max(nq, 1), DMATCH_DTYPE)
+        n = C.c_int(0)
+        check(lib().slam_amd_frame_match(self._h, _ptr(d1), _ptr(kp1), len(d1), _ptr(d2), _ptr(kp2), len(d2),
+                                          _ptr(ids_a), 0 if ids_a is None else len(ids_a), _ptr(xy),
+                                          max_dist, area, int(max_level), _ptr(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def frame_match_async(self, d_desc1, d_kp1, n1, d_n1, d_desc2, d_kp2, n2, d_n2, d_out, d_n_out,
+                          d_ids=None, n_ids=0, d_q_xy=None, max_dist=300.0, area=-1.0, max_level=4,
+                          stream=0):
+        check(lib().slam_amd_frame_match_async(self._h, _ptr(d_desc1), _ptr(d_kp1), n1, _ptr(d_n1),
+                                                _ptr(d_desc2), _ptr(d_kp2), n2, _ptr(d_n2),
+                                                _ptr(d_ids), n_ids, _ptr(d_q_xy), max_dist, area,
+                                                int(max_level), _ptr(d_out), _ptr(d_n_out),
+                                                C.c_void_p(stream)))
+
+    def frame_match_batch_async(self, batch, d_desc1, d_kp1, cap1, d_n1, d_desc2, d_kp2, cap2, d_n2,
+                                d_out, d_n_out, max_dist=300.0, area=-1.0, max_level=4, stream=0):
+        check(lib().slam_amd_frame_match_batch_async(self._h, batch, _ptr(d_desc1), _ptr(d_kp1), cap1,
+                                                      _ptr(d_n1), _ptr(d_desc2), _ptr(d_kp2), cap2,
+                                                      _ptr(d_n2), max_dist, area, int(max_level),
+                                                      _ptr(d_out), _ptr(d_n_out), C.c_void_p(stream)))
+
+    def match_pairs_async(self, d_desc, d_kp, n_keyframes, n_per, d_pairs, n_pairs, d_out,
+                          max_dist=300.0, area=-1.0, max_level=-1, stream=0):
+        check(lib().slam_amd_match_pairs_async(self._h, _ptr(d_desc), _ptr(d_kp), n_keyframes, n_per,
+                                                _ptr(d_pairs), n_pairs, max_dist, area, int(max_level),
+                                                _ptr(d_out), C.c_void_p(stream)))
+
+    def project_points(self, Rt, K4, dist5, xyz):
+        Rt = np.ascontiguousarray(Rt, np.float64).reshape(12)
+        K4 = np.ascontiguousarray(K4, np.float64).reshape(4)
+        d5 = None if dist5 is None else np.ascontiguousarray(dist5, np.float64).reshape(5)
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        uv = np.zeros((len(xyz), 2), np.float32)
+        check(lib().slam_amd_project_points(self._h, _ptr(Rt), _ptr(K4), _ptr(d5), _ptr(xyz), len(xyz),
+                                             _ptr(uv)))
+        return uv
+
+    def duplicate_pairs(self, d1, p1, d2, p2, desc_dist=100, point_dist=1e-2):
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 3)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 3)
+        flag = np.zeros((len(d1), len(d2)), np.uint8)
+        check(lib().slam_amd_duplicate_pairs(self._h, _ptr(d1), _ptr(p1), len(d1), _ptr(d2), _ptr(p2),
+                                              len(d2), int(desc_dist), float(point_dist), _ptr(flag)))
+        return flag

@@ -1,0 +1,683 @@
+// C ABI of the gfx950 ORB frontend: contexts, geometry, launch sequencing.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "detmath.h"
+#include "kernels.h"
+
+namespace sa {
+
+// ---- error plumbing -----------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    g_last_error = std::string(what) + " failed: " + hipGetErrorString(e) + " (" + file + ":" +
+                   std::to_string(line) + ")";
+    (void)hipGetLastError();
+    return SLAM_AMD_ERR_HIP;
+}
+
+// ---- a device buffer that grows, never shrinks ---------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return SLAM_AMD_OK;
+        if (p) { SA_HIP(hipFree(p)); p = nullptr; cap = 0; }
+        size_t want = std::max(bytes, (size_t)4096);
+        SA_HIP(hipMalloc(&p, want));
+        cap = want;
+        return SLAM_AMD_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+static int use_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        SA_FAIL(SLAM_AMD_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    }
+    if (device < 0 || device >= n) SA_FAIL(SLAM_AMD_ERR_ARG, "device index out of range");
+    SA_HIP(hipSetDevice(device));
+    return SLAM_AMD_OK;
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+// =============================================================================
+// Extractor
+// =============================================================================
+struct slam_amd_extractor {
+    slam_amd_orb_params params;
+    int width = 0, height = 0, max_batch = 0, max_keypoints = 0, device = 0;
+    PyrGeom g;
+    // per level (>= 1) resize tables on the device and LDS footprint
+    DevBuf tables;
+    const int* xoff[kMaxLevels] = {};
+    const uint16_t* xc1[kMaxLevels] = {};
+    const int* yoff[kMaxLevels] = {};
+    const uint16_t* yc1[kMaxLevels] = {};
+    int lds_pitch[kMaxLevels] = {}, lds_rows[kMaxLevels] = {};
+    DevBuf pyr, smap, hist, rowcnt, sel, kpxy;
+    // host-call staging
+    DevBuf h_img, h_kp, h_desc, h_count;
+    int h_img_pitch = 0;
+    hipStream_t stream = nullptr;
+    // geometry of the last batch (debug accessor)
+    const uint8_t* last_img0 = nullptr;
+    size_t last_frame_pitch = 0;
+    int last_row_stride = 0;
+};
+
+static int check_orb_params(const slam_amd_orb_params* p) {
+    if (!p) SA_FAIL(SLAM_AMD_ERR_ARG, "params is null");
+    if (p->nlevels < 1 || p->nlevels > kMaxLevels) SA_FAIL(SLAM_AMD_ERR_ARG, "nlevels out of range");
+    if (p->nfeatures < 0) SA_FAIL(SLAM_AMD_ERR_ARG, "nfeatures < 0");
+    if (!(p->scale_factor > 1.0f)) SA_FAIL(SLAM_AMD_ERR_ARG, "scale_factor must be > 1");
+    if (p->fast_threshold < 0 || p->fast_threshold > 255) SA_FAIL(SLAM_AMD_ERR_ARG, "fast_threshold out of range");
+    if (p->first_level != 0) SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "first_level != 0 is not implemented");
+    if (p->wta_k != 2) SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "WTA_K != 2 is not implemented");
+    if (p->score_type != 1) SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "only FAST_SCORE is implemented");
+    if (p->patch_size != 31) SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "patch_size != 31 is not implemented");
+    if (p->edge_threshold < 31) SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "edge_threshold < 31 is not implemented");
+    return SLAM_AMD_OK;
+}
+
+// One axis of the bit-exact bilinear resize: source offset and 8.8 weight of the
+// second tap for every destination index.  Double arithmetic, one rounding per
+// operation: scale = 1 / (dst / src); f = scale * (d + 0.5) - 0.5.
+static void linear_exact_axis(int src, int dst, bool exact_half, int32_t* off, uint16_t* c1) {
+    if (exact_half) {
+        for (int d = 0; d < dst; d++) { off[d] = 2 * d; c1[d] = 128; }
+        return;
+    }
+    const double ratio = (double)dst / (double)src;
+    const double scale = 1.0 / ratio;
+    for (int d = 0; d < dst; d++) {
+        double f = scale * ((double)d + 0.5);
+        f -= 0.5;
+        const int i = (int)floor(f);
+        if (i < 0 || src <= 1) { off[d] = 0; c1[d] = 0; }
+        else if (i >= src - 1) { off[d] = src - 1; c1[d] = 0; }
+        else { off[d] = i; c1[d] = (uint16_t)lrint((f - (double)i) * 256.0); }
+    }
+}
+
+static int build_geometry(slam_amd_extractor* ex) {
+    const slam_amd_orb_params& p = ex->params;
+    PyrGeom& g = ex->g;
+    memset(&g, 0, sizeof g);
+    g.nlevels = p.nlevels;
+    g.edge = p.edge_threshold;
+    g.fast_threshold = p.fast_threshold;
+    // per-level quotas: geometric series in float, as ORB computes them
+    const float factor = (float)(1.0 / (double)p.scale_factor);
+    float desired = (float)p.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)p.nlevels));
+    int sum = 0;
+    unsigned off = 0;
+    int rows = 0, tiles = 0;
+    for (int l = 0; l < p.nlevels; l++) {
+        LevelGeom& L = g.lv[l];
+        L.scale = (float)pow((double)p.scale_factor, (double)l);
+        L.inv_scale = 1.0f / L.scale;
+        L.w = (int)lrintf((float)ex->width * L.inv_scale);
+        L.h = (int)lrintf((float)ex->height * L.inv_scale);
+        if (L.w <= 0 || L.h <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "image too small for the number of levels");
+        L.size = (float)p.patch_size * L.scale;
+        if (l < p.nlevels - 1) {
+            L.quota = (int)lrintf(desired);
+            sum += L.quota;
+            desired *= factor;
+        } else {
+            L.quota = std::max(p.nfeatures - sum, 0);
+        }
+        L.tiles_x = div_up(L.w, kFastTileW);
+        L.pitch = L.tiles_x * kFastTileW;
+        L.off = off;
+        L.row_base = rows;
+        L.tile_base = tiles;
+        off += (unsigned)L.pitch * (unsigned)L.h;
+        rows += L.h;
+        tiles += L.tiles_x * div_up(L.h, kFastTileH);
+    }
+    g.frame_bytes = (off + 255u) & ~255u;
+    g.total_rows = rows;
+    g.total_tiles = tiles;
+    return SLAM_AMD_OK;
+}
+
+static int build_tables(slam_amd_extractor* ex) {
+    const PyrGeom& g = ex->g;
+    // layout: per level l >= 1: xoff[w] yoff[h] (int32) then xc1[w] yc1[h] (uint16), 16-byte aligned
+    std::vector<uint8_t> host;
+    std::vector<size_t> o_xoff(g.nlevels), o_yoff(g.nlevels), o_xc(g.nlevels), o_yc(g.nlevels);
+    auto reserve = [&](size_t bytes) { size_t o = (host.size() + 15) & ~(size_t)15; host.resize(o + bytes); return o; };
+    for (int l = 1; l < g.nlevels; l++) {
+        const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h, dw = g.lv[l].w, dh = g.lv[l].h;
+        o_xoff[l] = reserve(sizeof(int32_t) * dw);
+        o_yoff[l] = reserve(sizeof(int32_t) * dh);
+        o_xc[l] = reserve(sizeof(uint16_t) * dw);
+        o_yc[l] = reserve(sizeof(uint16_t) * dh);
+        int32_t* xo = reinterpret_cast<int32_t*>(host.data() + o_xoff[l]);
+        int32_t* yo = reinterpret_cast<int32_t*>(host.data() + o_yoff[l]);
+        uint16_t* xc = reinterpret_cast<uint16_t*>(host.data() + o_xc[l]);
+        uint16_t* yc = reinterpret_cast<uint16_t*>(host.data() + o_yc[l]);
+        const bool half = (sw == 2 * dw) && (sh == 2 * dh);
+        linear_exact_axis(sw, dw, half, xo, xc);
+        linear_exact_axis(sh, dh, half, yo, yc);
+        // LDS footprint of the widest / tallest destination tile
+        int max_cols = 0, max_rows = 0;
+        for (int x0 = 0; x0 < dw; x0 += 128) {
+            const int xl = std::min(x0 + 128, dw) - 1;
+            const int s0 = xo[x0] & ~3, s1 = std::min(xo[xl] + 1, sw - 1);
+            max_cols = std::max(max_cols, ((s1 - s0) / 4 + 1) * 4);
+        }
+        for (int y0 = 0; y0 < dh; y0 += 16) {
+            const int yl = std::min(y0 + 16, dh) - 1;
+            const int s0 = yo[y0], s1 = std::min(yo[yl] + 1, sh - 1);
+            max_rows = std::max(max_rows, s1 - s0 + 1);
+        }
+        ex->lds_pitch[l] = max_cols + 4;
+        ex->lds_rows[l] = max_rows;
+        if ((size_t)ex->lds_pitch[l] * ex->lds_rows[l] > 64 * 1024)
+            SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "scale factor too large for the resize tile");
+    }
+    if (host.empty()) host.resize(16);
+    int rc = ex->tables.reserve(host.size());
+    if (rc) return rc;
+    SA_HIP(hipMemcpy(ex->tables.p, host.data(), host.size(), hipMemcpyHostToDevice));
+    const uint8_t* base = ex->tables.as<uint8_t>();
+    for (int l = 1; l < g.nlevels; l++) {
+        ex->xoff[l] = reinterpret_cast<const int*>(base + o_xoff[l]);
+        ex->yoff[l] = reinterpret_cast<const int*>(base + o_yoff[l]);
+        ex->xc1[l] = reinterpret_cast<const uint16_t*>(base + o_xc[l]);
+        ex->yc1[l] = reinterpret_cast<const uint16_t*>(base + o_yc[l]);
+    }
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int width, int height,
+                                         int max_batch, int max_keypoints, int device,
+                                         slam_amd_extractor** out) {
+    if (!out) SA_FAIL(SLAM_AMD_ERR_ARG, "out is null");
+    *out = nullptr;
+    int rc = check_orb_params(params);
+    if (rc) return rc;
+    if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
+        SA_FAIL(SLAM_AMD_ERR_ARG, "image size out of range");
+    if (max_batch <= 0 || max_batch > 65535) SA_FAIL(SLAM_AMD_ERR_ARG, "max_batch out of range");
+    if (max_keypoints <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "max_keypoints must be positive");
+    rc = use_device(device);
+    if (rc) return rc;
+    slam_amd_extractor* ex = new (std::nothrow) slam_amd_extractor();
+    if (!ex) SA_FAIL(SLAM_AMD_ERR_NOMEM, "out of host memory");
+    ex->params = *params;
+    ex->width = width; ex->height = height;
+    ex->max_batch = max_batch; ex->max_keypoints = max_keypoints; ex->device = device;
+    auto fail = [&](int code) { slam_amd_extractor_destroy(ex); return code; };
+    if ((rc = build_geometry(ex))) return fail(rc);
+    if ((rc = build_tables(ex))) return fail(rc);
+    const PyrGeom& g = ex->g;
+    const size_t B = (size_t)max_batch;
+    if ((rc = ex->pyr.reserve(B * g.frame_bytes))) return fail(rc);
+    if ((rc = ex->smap.reserve(B * g.frame_bytes))) return fail(rc);
+    if ((rc = ex->hist.reserve(B * g.nlevels * 256 * sizeof(unsigned)))) return fail(rc);
+    if ((rc = ex->rowcnt.reserve(B * g.total_rows * sizeof(unsigned)))) return fail(rc);
+    if ((rc = ex->sel.reserve(B * sizeof(FrameSelect)))) return fail(rc);
+    if ((rc = ex->kpxy.reserve(B * (size_t)max_keypoints * sizeof(uint32_t)))) return fail(rc);
+    hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__));
+    *out = ex;
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_extractor_destroy(slam_amd_extractor* ex) {
+    if (!ex) return SLAM_AMD_OK;
+    (void)hipSetDevice(ex->device);
+    if (ex->stream) { (void)hipStreamSynchronize(ex->stream); (void)hipStreamDestroy(ex->stream); }
+    for (DevBuf* b : {&ex->tables, &ex->pyr, &ex->smap, &ex->hist, &ex->rowcnt, &ex->sel, &ex->kpxy,
+                      &ex->h_img, &ex->h_kp, &ex->h_desc, &ex->h_count})
+        b->release();
+    delete ex;
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_extractor_levels(const slam_amd_extractor* ex, int* nlevels, int* widths,
+                                         int* heights, int* quotas, float* scales) {
+    if (!ex) SA_FAIL(SLAM_AMD_ERR_ARG, "extractor is null");
+    if (nlevels) *nlevels = ex->g.nlevels;
+    for (int l = 0; l < ex->g.nlevels; l++) {
+        if (widths) widths[l] = ex->g.lv[l].w;
+        if (heights) heights[l] = ex->g.lv[l].h;
+        if (quotas) quotas[l] = ex->g.lv[l].quota;
+        if (scales) scales[l] = ex->g.lv[l].scale;
+    }
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_t* d_images, int batch,
+                                            size_t frame_pitch, int row_stride,
+                                            slam_amd_keypoint* d_kp, uint8_t* d_desc, int32_t* d_count,
+                                            int capacity, void* stream) {
+    if (!ex || !d_images || !d_kp || !d_desc) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    if (batch <= 0 || batch > ex->max_batch) SA_FAIL(SLAM_AMD_ERR_ARG, "batch exceeds the context's max_batch");
+    if (capacity <= 0 || capacity > ex->max_keypoints)
+        SA_FAIL(SLAM_AMD_ERR_ARG, "capacity exceeds the context's max_keypoints");
+    if (row_stride < ex->width) SA_FAIL(SLAM_AMD_ERR_ARG, "row_stride smaller than the image width");
+    if (batch > 1 && frame_pitch < (size_t)row_stride * (ex->height - 1) + ex->width)
+        SA_FAIL(SLAM_AMD_ERR_ARG, "frame_pitch smaller than one frame");
+    if ((reinterpret_cast<uintptr_t>(d_desc) & 15) || (reinterpret_cast<uintptr_t>(d_kp) & 3))
+        SA_FAIL(SLAM_AMD_ERR_ARG, "d_desc must be 16-byte aligned, d_kp 4-byte aligned");
+    SA_HIP(hipSetDevice(ex->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const PyrGeom& g = ex->g;
+    const int aligned = ((reinterpret_cast<uintptr_t>(d_images) & 3) == 0) && (row_stride % 4 == 0) &&
+                        (batch == 1 || frame_pitch % 4 == 0);
+    ex->last_img0 = d_images; ex->last_frame_pitch = frame_pitch; ex->last_row_stride = row_stride;
+
+    SA_HIP(hipMemsetAsync(ex->hist.p, 0, (size_t)batch * g.nlevels * 256 * sizeof(unsigned), st));
+    int rc;
+    for (int l = 1; l < g.nlevels; l++) {
+        ResizeArgs a;
+        if (l == 1) {
+            a.src = d_images; a.src_frame_pitch = frame_pitch; a.src_pitch = row_stride; a.src_aligned = aligned;
+        } else {
+            a.src = ex->pyr.as<uint8_t>() + g.lv[l - 1].off; a.src_frame_pitch = g.frame_bytes;
+            a.src_pitch = g.lv[l - 1].pitch; a.src_aligned = 1;
+        }
+        a.sw = g.lv[l - 1].w; a.sh = g.lv[l - 1].h;
+        a.dst = ex->pyr.as<uint8_t>() + g.lv[l].off; a.dst_frame_pitch = g.frame_bytes;
+        a.dst_pitch = g.lv[l].pitch; a.dw = g.lv[l].w; a.dh = g.lv[l].h;
+        a.xoff = ex->xoff[l]; a.xc1 = ex->xc1[l]; a.yoff = ex->yoff[l]; a.yc1 = ex->yc1[l];
+        a.lds_pitch = ex->lds_pitch[l]; a.lds_rows = ex->lds_rows[l];
+        if ((rc = launch_resize(a, batch, st))) return rc;
+    }
+    FastArgs fa;
+    fa.img0 = d_images; fa.img0_frame_pitch = frame_pitch; fa.img0_pitch = row_stride; fa.img0_aligned = aligned;
+    fa.pyr = ex->pyr.as<uint8_t>(); fa.smap = ex->smap.as<uint8_t>(); fa.hist = ex->hist.as<unsigned>(); fa.g = g;
+    if ((rc = launch_fast(fa, batch, st))) return rc;
+    SelectArgs sa_;
+    sa_.hist = ex->hist.as<unsigned>(); sa_.sel = ex->sel.as<FrameSelect>(); sa_.d_count = d_count; sa_.g = g;
+    if ((rc = launch_select(sa_, batch, st))) return rc;
+    CompactArgs ca;
+    ca.smap = ex->smap.as<uint8_t>(); ca.sel = ex->sel.as<FrameSelect>(); ca.rowcnt = ex->rowcnt.as<unsigned>();
+    ca.kp = d_kp; ca.kpxy = ex->kpxy.as<uint32_t>(); ca.capacity = capacity; ca.g = g;
+    if ((rc = launch_compact(ca, batch, st))) return rc;
+    DescribeArgs da;
+    da.img0 = d_images; da.img0_frame_pitch = frame_pitch; da.img0_pitch = row_stride;
+    da.pyr = ex->pyr.as<uint8_t>(); da.sel = ex->sel.as<FrameSelect>(); da.kp = d_kp;
+    da.kpxy = ex->kpxy.as<uint32_t>(); da.desc = d_desc; da.capacity = capacity; da.g = g;
+    if ((rc = launch_describe(da, batch, st))) return rc;
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_extract(slam_amd_extractor* ex, const uint8_t* gray, int width, int height,
+                                int stride, slam_amd_keypoint* kp_out, uint8_t* desc_out,
+                                int capacity, int* n_out) {
+    if (!ex || !n_out) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    *n_out = 0;
+    if (!gray || width <= 0 || height <= 0) return SLAM_AMD_OK;  // empty image -> empty result (frame.cpp:24)
+    if (width != ex->width || height != ex->height)
+        SA_FAIL(SLAM_AMD_ERR_ARG, "image size differs from the size the extractor was created for");
+    if (stride < width) SA_FAIL(SLAM_AMD_ERR_ARG, "stride smaller than width");
+    if (capacity < 0 || (capacity > 0 && (!kp_out || !desc_out))) SA_FAIL(SLAM_AMD_ERR_ARG, "null output");
+    SA_HIP(hipSetDevice(ex->device));
+    int rc;
+    ex->h_img_pitch = (width + 63) & ~63;
+    if ((rc = ex->h_img.reserve((size_t)ex->h_img_pitch * height))) return rc;
+    const int cap = ex->max_keypoints;
+    if ((rc = ex->h_kp.reserve((size_t)cap * sizeof(slam_amd_keypoint)))) return rc;
+    if ((rc = ex->h_desc.reserve((size_t)cap * 32))) return rc;
+    if ((rc = ex->h_count.reserve(sizeof(int32_t)))) return rc;
+    SA_HIP(hipMemcpy2DAsync(ex->h_img.p, ex->h_img_pitch, gray, stride, width, height,
+                            hipMemcpyHostToDevice, ex->stream));
+    rc = slam_amd_extract_batch_async(ex, ex->h_img.as<uint8_t>(), 1, 0, ex->h_img_pitch,
+                                      ex->h_kp.as<slam_amd_keypoint>(), ex->h_desc.as<uint8_t>(),
+                                      ex->h_count.as<int32_t>(), cap, ex->stream);
+    if (rc) return rc;
+    int32_t n = 0;
+    SA_HIP(hipMemcpyAsync(&n, ex->h_count.p, sizeof n, hipMemcpyDeviceToHost, ex->stream));
+    SA_HIP(hipStreamSynchronize(ex->stream));
+    *n_out = n;
+    if (n > cap) SA_FAIL(SLAM_AMD_ERR_CAPACITY, "more keypoints than the extractor's max_keypoints");
+    if (n > capacity) SA_FAIL(SLAM_AMD_ERR_CAPACITY, "more keypoints than the caller's capacity");
+    if (n > 0) {
+        SA_HIP(hipMemcpyAsync(kp_out, ex->h_kp.p, (size_t)n * sizeof(slam_amd_keypoint), hipMemcpyDeviceToHost, ex->stream));
+        SA_HIP(hipMemcpyAsync(desc_out, ex->h_desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, ex->stream));
+        SA_HIP(hipStreamSynchronize(ex->stream));
+    }
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_extractor_debug_level(slam_amd_extractor* ex, int frame, int level,
+                                              uint8_t* host_out, int host_stride) {
+    if (!ex || !host_out) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    if (level < 0 || level >= ex->g.nlevels || frame < 0 || frame >= ex->max_batch)
+        SA_FAIL(SLAM_AMD_ERR_ARG, "level or frame out of range");
+    const LevelGeom& L = ex->g.lv[level];
+    if (host_stride < L.w) SA_FAIL(SLAM_AMD_ERR_ARG, "host_stride too small");
+    SA_HIP(hipSetDevice(ex->device));
+    SA_HIP(hipDeviceSynchronize());
+    if (level == 0) {
+        if (!ex->last_img0) SA_FAIL(SLAM_AMD_ERR_ARG, "no batch has been processed yet");
+        SA_HIP(hipMemcpy2D(host_out, host_stride, ex->last_img0 + (size_t)frame * ex->last_frame_pitch,
+                           ex->last_row_stride, L.w, L.h, hipMemcpyDeviceToHost));
+    } else {
+        SA_HIP(hipMemcpy2D(host_out, host_stride,
+                           ex->pyr.as<uint8_t>() + (size_t)frame * ex->g.frame_bytes + L.off, L.pitch,
+                           L.w, L.h, hipMemcpyDeviceToHost));
+    }
+    return SLAM_AMD_OK;
+}
+
+// =============================================================================
+// Matcher
+// =============================================================================
+struct slam_amd_matcher {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    DevBuf best;                       // running keys of the async calls
+    DevBuf h_d1, h_k1, h_d2, h_k2, h_ids, h_xy, h_out, h_n, h_aux;  // host-call staging
+};
+
+extern "C" int slam_amd_matcher_create(int device, slam_amd_matcher** out) {
+    if (!out) SA_FAIL(SLAM_AMD_ERR_ARG, "out is null");
+    *out = nullptr;
+    int rc = use_device(device);
+    if (rc) return rc;
+    slam_amd_matcher* m = new (std::nothrow) slam_amd_matcher();
+    if (!m) SA_FAIL(SLAM_AMD_ERR_NOMEM, "out of host memory");
+    m->device = device;
+    int cu = 0;
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0)
+        m->n_cu = cu;
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete m; return hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__); }
+    *out = m;
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_matcher_destroy(slam_amd_matcher* m) {
+    if (!m) return SLAM_AMD_OK;
+    (void)hipSetDevice(m->device);
+    if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
+    for (DevBuf* b : {&m->best, &m->h_d1, &m->h_k1, &m->h_d2, &m->h_k2, &m->h_ids, &m->h_xy, &m->h_out,
+                      &m->h_n, &m->h_aux})
+        b->release();
+    delete m;
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_matcher_reserve(slam_amd_matcher* m, size_t query_rows) {
+    if (!m) SA_FAIL(SLAM_AMD_ERR_ARG, "matcher is null");
+    SA_HIP(hipSetDevice(m->device));
+    return m->best.reserve(query_rows * sizeof(unsigned));
+}
+
+static int dmax_of(float max_dist) {
+    if (!(max_dist >= 0.f)) return -1;  // also NaN
+    if (max_dist >= 256.f) return 256;
+    return (int)floorf(max_dist);
+}
+
+static int match_common(slam_amd_matcher* m, int batch,
+                        const uint8_t* d1, const slam_amd_keypoint* k1, int n1, const int32_t* d_n1, int cap1,
+                        const uint8_t* d2, const slam_amd_keypoint* k2, int n2, const int32_t* d_n2, int cap2,
+                        const int32_t* ids, int n_ids, const float* q_xy,
+                        float max_dist, float area, int max_level,
+                        slam_amd_dmatch* d_out, int32_t* d_n_out, hipStream_t st) {
+    if (!m || !d_out || !d_n_out) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    if (n1 < 0 || n2 < 0 || n_ids < 0 || batch <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "negative size");
+    if (n2 >= (1 << 20)) SA_FAIL(SLAM_AMD_ERR_ARG, "train set larger than 2^20 - 1 rows");
+    const bool gated = (area != -1.f) || (max_level != -1);
+    if (ids && n_ids == 0) ids = nullptr;
+    if ((n1 > 0 && !d1) || (n2 > 0 && !d2)) SA_FAIL(SLAM_AMD_ERR_ARG, "null descriptor pointer");
+    if (gated && ((n1 > 0 && !k1 && !(q_xy && max_level == -1)) || (n2 > 0 && !k2)))
+        SA_FAIL(SLAM_AMD_ERR_ARG, "keypoints are required when a gate is on");
+    if ((reinterpret_cast<uintptr_t>(d1) & 15) || (reinterpret_cast<uintptr_t>(d2) & 15))
+        SA_FAIL(SLAM_AMD_ERR_ARG, "descriptor pointers must be 16-byte aligned");
+    SA_HIP(hipSetDevice(m->device));
+    const int nq = ids ? n_ids : n1;
+    const size_t rows = (size_t)batch * cap1;
+    int rc = m->best.reserve(std::max(rows, (size_t)1) * sizeof(unsigned));
+    if (rc) return rc;
+    SA_HIP(hipMemsetAsync(m->best.p, 0xff, std::max(rows, (size_t)1) * sizeof(unsigned), st));
+    MatchArgs a;
+    memset(&a, 0, sizeof a);
+    a.qdesc = d1; a.qkp = k1; a.d_n1 = d_n1; a.n1 = n1;
+    a.tdesc = d2; a.tkp = k2; a.d_n2 = d_n2; a.n2 = n2;
+    a.ids = ids; a.n_ids = n_ids; a.q_xy = q_xy; a.cap1 = cap1; a.cap2 = cap2;
+    a.area = area; a.max_level = max_level; a.dmax = dmax_of(max_dist);
+    a.best = m->best.as<unsigned>();
+    if ((rc = launch_match(a, batch, nq, n2, m->n_cu, st))) return rc;
+    FinalizeArgs f;
+    f.best = m->best.as<unsigned>(); f.d_n1 = d_n1; f.n1 = n1; f.ids = ids; f.n_ids = n_ids;
+    f.cap1 = cap1; f.dmax = a.dmax; f.out = d_out; f.n_out = d_n_out;
+    return launch_finalize(f, batch, st);
+}
+
+extern "C" int slam_amd_frame_match_async(slam_amd_matcher* m,
+                                          const uint8_t* d_desc1, const slam_amd_keypoint* d_kp1, int n1,
+                                          const int32_t* d_n1,
+                                          const uint8_t* d_desc2, const slam_amd_keypoint* d_kp2, int n2,
+                                          const int32_t* d_n2,
+                                          const int32_t* d_ids, int n_ids, const float* d_q_xy,
+                                          float max_dist, float area, int max_level,
+                                          slam_amd_dmatch* d_out, int32_t* d_n_out, void* stream) {
+    const int cap1 = std::max(d_ids ? std::max(n_ids, n1) : n1, 1);
+    return match_common(m, 1, d_desc1, d_kp1, n1, d_n1, cap1, d_desc2, d_kp2, n2, d_n2, std::max(n2, 1),
+                        d_ids, n_ids, d_q_xy, max_dist, area, max_level, d_out, d_n_out,
+                        reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int slam_amd_frame_match_batch_async(slam_amd_matcher* m, int batch,
+                                                const uint8_t* d_desc1, const slam_amd_keypoint* d_kp1,
+                                                int cap1, const int32_t* d_n1,
+                                                const uint8_t* d_desc2, const slam_amd_keypoint* d_kp2,
+                                                int cap2, const int32_t* d_n2,
+                                                float max_dist, float area, int max_level,
+                                                slam_amd_dmatch* d_out, int32_t* d_n_out, void* stream) {
+    if (cap1 <= 0 || cap2 <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "capacities must be positive");
+    if (!d_n1 || !d_n2) SA_FAIL(SLAM_AMD_ERR_ARG, "batched matching needs device counts");
+    return match_common(m, batch, d_desc1, d_kp1, cap1, d_n1, cap1, d_desc2, d_kp2, cap2, d_n2, cap2,
+                        nullptr, 0, nullptr, max_dist, area, max_level, d_out, d_n_out,
+                        reinterpret_cast<hipStream_t>(stream));
+}
+
+static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t st) {
+    int rc = b.reserve(std::max(bytes, (size_t)16));
+    if (rc) return rc;
+    if (bytes) SA_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_frame_match(slam_amd_matcher* m,
+                                    const uint8_t* desc1, const slam_amd_keypoint* kp1, int n1,
+                                    const uint8_t* desc2, const slam_amd_keypoint* kp2, int n2,
+                                    const int32_t* ids, int n_ids, const float* q_xy,
+                                    float max_dist, float area, int max_level,
+                                    slam_amd_dmatch* out, int* n_out) {
+    if (!m || !n_out) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    *n_out = 0;
+    if (n1 < 0 || n2 < 0 || n_ids < 0) SA_FAIL(SLAM_AMD_ERR_ARG, "negative size");
+    if (ids && n_ids == 0) ids = nullptr;
+    const int nq = ids ? n_ids : n1;
+    if (nq == 0 || n2 == 0) return SLAM_AMD_OK;  // radiusMatch on an empty set yields no matches
+    if (!out) SA_FAIL(SLAM_AMD_ERR_ARG, "out is null");
+    if (!desc1 || !desc2) SA_FAIL(SLAM_AMD_ERR_ARG, "null descriptor pointer");
+    if (ids)
+        for (int i = 0; i < n_ids; i++)
+            if (ids[i] < 0 || ids[i] >= n1) SA_FAIL(SLAM_AMD_ERR_ARG, "id out of range");
+    SA_HIP(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    int rc;
+    if ((rc = upload(m->h_d1, desc1, (size_t)n1 * 32, st))) return rc;
+    if ((rc = upload(m->h_d2, desc2, (size_t)n2 * 32, st))) return rc;
+    if (kp1 && (rc = upload(m->h_k1, kp1, (size_t)n1 * sizeof(slam_amd_keypoint), st))) return rc;
+    if (kp2 && (rc = upload(m->h_k2, kp2, (size_t)n2 * sizeof(slam_amd_keypoint), st))) return rc;
+    if (ids && (rc = upload(m->h_ids, ids, (size_t)n_ids * sizeof(int32_t), st))) return rc;
+    if (q_xy && (rc = upload(m->h_xy, q_xy, (size_t)nq * 2 * sizeof(float), st))) return rc;
+    if ((rc = m->h_out.reserve((size_t)std::max(nq, n1) * sizeof(slam_amd_dmatch)))) return rc;
+    if ((rc = m->h_n.reserve(sizeof(int32_t)))) return rc;
+    rc = slam_amd_frame_match_async(m, m->h_d1.as<uint8_t>(), kp1 ? m->h_k1.as<slam_amd_keypoint>() : nullptr, n1,
+                                    nullptr, m->h_d2.as<uint8_t>(), kp2 ? m->h_k2.as<slam_amd_keypoint>() : nullptr,
+                                    n2, nullptr, ids ? m->h_ids.as<int32_t>() : nullptr, n_ids,
+                                    q_xy ? m->h_xy.as<float>() : nullptr, max_dist, area, max_level,
+                                    m->h_out.as<slam_amd_dmatch>(), m->h_n.as<int32_t>(), st);
+    if (rc) return rc;
+    int32_t n = 0;
+    SA_HIP(hipMemcpyAsync(&n, m->h_n.p, sizeof n, hipMemcpyDeviceToHost, st));
+    SA_HIP(hipStreamSynchronize(st));
+    if (n > 0) {
+        SA_HIP(hipMemcpyAsync(out, m->h_out.p, (size_t)n * sizeof(slam_amd_dmatch), hipMemcpyDeviceToHost, st));
+        SA_HIP(hipStreamSynchronize(st));
+    }
+    *n_out = n;
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_match_pairs_async(slam_amd_matcher* m,
+                                          const uint8_t* d_desc, const slam_amd_keypoint* d_kp,
+                                          int n_keyframes, int n_per,
+                                          const int32_t* d_pairs, int n_pairs,
+                                          float max_dist, float area, int max_level,
+                                          uint32_t* d_out, void* stream) {
+    if (!m || !d_desc || !d_pairs || !d_out) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    if (n_keyframes <= 0 || n_per <= 0 || n_pairs < 0) SA_FAIL(SLAM_AMD_ERR_ARG, "bad size");
+    if (n_per > 65535) SA_FAIL(SLAM_AMD_ERR_ARG, "n_per exceeds 65535 (16-bit train index in the result)");
+    const bool gated = (area != -1.f) || (max_level != -1);
+    if (gated && !d_kp) SA_FAIL(SLAM_AMD_ERR_ARG, "keypoints are required when a gate is on");
+    if (reinterpret_cast<uintptr_t>(d_desc) & 15) SA_FAIL(SLAM_AMD_ERR_ARG, "d_desc must be 16-byte aligned");
+    SA_HIP(hipSetDevice(m->device));
+    MatchArgs a;
+    memset(&a, 0, sizeof a);
+    a.qdesc = d_desc; a.qkp = d_kp; a.tdesc = d_desc; a.tkp = d_kp;
+    a.area = area; a.max_level = max_level; a.dmax = dmax_of(max_dist);
+    a.pairs = d_pairs; a.n_per = n_per; a.pair_out = d_out;
+    return launch_match_pairs(a, n_pairs, reinterpret_cast<hipStream_t>(stream));
+}
+
+// =============================================================================
+// Projection, duplicates
+// =============================================================================
+extern "C" int slam_amd_project_points_async(slam_amd_matcher* m, const double* Rt, const double* K4,
+                                             const double* dist5, const float* d_xyz, int n, float* d_uv,
+                                             void* stream) {
+    if (!m || !Rt || !K4) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    if (n < 0) SA_FAIL(SLAM_AMD_ERR_ARG, "negative size");
+    if (n == 0) return SLAM_AMD_OK;
+    if (!d_xyz || !d_uv) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    SA_HIP(hipSetDevice(m->device));
+    ProjectArgs a;
+    memcpy(a.Rt, Rt, sizeof a.Rt);
+    memcpy(a.K4, K4, sizeof a.K4);
+    for (int i = 0; i < 5; i++) a.dist[i] = dist5 ? dist5[i] : 0.0;
+    a.xyz = d_xyz; a.uv = d_uv; a.n = n;
+    return launch_project(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int slam_amd_project_points(slam_amd_matcher* m, const double* Rt, const double* K4,
+                                       const double* dist5, const float* xyz, int n, float* uv) {
+    if (!m) SA_FAIL(SLAM_AMD_ERR_ARG, "matcher is null");
+    if (n < 0) SA_FAIL(SLAM_AMD_ERR_ARG, "negative size");
+    if (n == 0) return SLAM_AMD_OK;
+    if (!xyz || !uv) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    SA_HIP(hipSetDevice(m->device));
+    int rc;
+    if ((rc = upload(m->h_xy, xyz, (size_t)n * 3 * sizeof(float), m->stream))) return rc;
+    if ((rc = m->h_aux.reserve((size_t)n * 2 * sizeof(float)))) return rc;
+    rc = slam_amd_project_points_async(m, Rt, K4, dist5, m->h_xy.as<float>(), n, m->h_aux.as<float>(), m->stream);
+    if (rc) return rc;
+    SA_HIP(hipMemcpyAsync(uv, m->h_aux.p, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    SA_HIP(hipStreamSynchronize(m->stream));
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_duplicate_pairs(slam_amd_matcher* m,
+                                        const uint8_t* desc1, const float* pos1, int n1,
+                                        const uint8_t* desc2, const float* pos2, int n2,
+                                        int desc_dist, double point_dist, uint8_t* flag) {
+    if (!m) SA_FAIL(SLAM_AMD_ERR_ARG, "matcher is null");
+    if (n1 < 0 || n2 < 0) SA_FAIL(SLAM_AMD_ERR_ARG, "negative size");
+    if (n1 == 0 || n2 == 0) return SLAM_AMD_OK;
+    if (!desc1 || !desc2 || !pos1 || !pos2 || !flag) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    SA_HIP(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    int rc;
+    if ((rc = upload(m->h_d1, desc1, (size_t)n1 * 32, st))) return rc;
+    if ((rc = upload(m->h_d2, desc2, (size_t)n2 * 32, st))) return rc;
+    if ((rc = upload(m->h_k1, pos1, (size_t)n1 * 3 * sizeof(float), st))) return rc;
+    if ((rc = upload(m->h_k2, pos2, (size_t)n2 * 3 * sizeof(float), st))) return rc;
+    if ((rc = m->h_aux.reserve((size_t)n1 * n2))) return rc;
+    DupArgs a;
+    a.d1 = m->h_d1.as<uint8_t>(); a.p1 = m->h_k1.as<float>(); a.n1 = n1;
+    a.d2 = m->h_d2.as<uint8_t>(); a.p2 = m->h_k2.as<float>(); a.n2 = n2;
+    a.desc_dist = desc_dist; a.point_dist = point_dist; a.flag = m->h_aux.as<uint8_t>();
+    if ((rc = launch_duplicates(a, st))) return rc;
+    SA_HIP(hipMemcpyAsync(flag, m->h_aux.p, (size_t)n1 * n2, hipMemcpyDeviceToHost, st));
+    SA_HIP(hipStreamSynchronize(st));
+    return SLAM_AMD_OK;
+}
+
+// =============================================================================
+// General
+// =============================================================================
+extern "C" int slam_amd_version(void) { return SLAM_AMD_VERSION; }
+
+extern "C" const char* slam_amd_status_string(int status) {
+    switch (status) {
+        case SLAM_AMD_OK: return "ok";
+        case SLAM_AMD_ERR_ARG: return "invalid argument";
+        case SLAM_AMD_ERR_UNSUPPORTED: return "unsupported ORB variant";
+        case SLAM_AMD_ERR_CAPACITY: return "output capacity exceeded";
+        case SLAM_AMD_ERR_NOMEM: return "out of memory";
+        case SLAM_AMD_ERR_HIP: return "HIP runtime error";
+        case SLAM_AMD_ERR_NO_DEVICE: return "no GPU device";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char* slam_amd_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int slam_amd_device_count(int* count) {
+    if (!count) SA_FAIL(SLAM_AMD_ERR_ARG, "count is null");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return SLAM_AMD_OK;
+}
+
+extern "C" void slam_amd_default_orb_params(slam_amd_orb_params* p) {
+    if (!p) return;
+    p->nfeatures = 1000; p->scale_factor = 1.2f; p->nlevels = 8; p->edge_threshold = 31;
+    p->first_level = 0; p->wta_k = 2; p->score_type = 1; p->patch_size = 31; p->fast_threshold = 20;
+}
+
+extern "C" void slam_amd_sincos_f32(float angle_rad, float* cos_out, float* sin_out) {
+    float c, s;
+    sincos_f32(angle_rad, &c, &s);
+    if (cos_out) *cos_out = c;
+    if (sin_out) *sin_out = s;
+}
+
+extern "C" float slam_amd_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
+
+extern "C" int slam_amd_linear_exact_coeffs(int src_size, int dst_size, int32_t* offsets, uint16_t* c1) {
+    if (src_size <= 0 || dst_size <= 0 || !offsets || !c1) SA_FAIL(SLAM_AMD_ERR_ARG, "bad argument");
+    linear_exact_axis(src_size, dst_size, false, offsets, c1);
+    return SLAM_AMD_OK;
+}

@@ -1,0 +1,68 @@
+// Shared declarations of the gfx950 ORB frontend library (host + device).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/slam_amd.h"
+
+namespace sa {
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define SA_HIP(call)                                                        \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) return sa::hip_fail(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define SA_FAIL(code, msg)      \
+    do {                        \
+        sa::set_error(msg);     \
+        return (code);          \
+    } while (0)
+
+constexpr int kMaxLevels = SLAM_AMD_MAX_LEVELS;
+
+// Geometry of one pyramid level, shared by every kernel.  Level 0 is read from
+// the caller's image; levels >= 1 live in the context's pyramid buffer.
+struct LevelGeom {
+    int w, h;           // level size in pixels
+    int pitch;          // bytes per row in the pyramid / survivor-map buffers
+    int quota;          // per-level keypoint quota (retain-best cut)
+    unsigned off;       // byte offset of the level inside one frame's buffer
+    int row_base;       // index of the level's first row among all rows of a frame
+    int tile_base;      // index of the level's first FAST tile among all tiles of a frame
+    int tiles_x;        // FAST tiles per row of tiles
+    float scale;        // level scale (float(pow(scale_factor, level)))
+    float inv_scale;    // 1.0f / scale
+    float size;         // keypoint size at this level: patch_size * scale
+};
+
+struct PyrGeom {
+    int nlevels;
+    int edge;           // edge threshold
+    int fast_threshold;
+    int total_rows;     // sum of level heights
+    int total_tiles;    // FAST tiles per frame
+    unsigned frame_bytes;  // bytes of one frame's pyramid (and survivor map)
+    LevelGeom lv[kMaxLevels];
+};
+
+// Result of the per-frame selection step.
+struct FrameSelect {
+    int cut[kMaxLevels];    // keep survivors with score >= cut (256: keep none)
+    int count[kMaxLevels];  // survivors kept per level
+    int offset[kMaxLevels]; // index of the level's first keypoint in the frame's output
+    int total;
+    int pad[3];
+};
+
+constexpr int kFastTileW = 64;
+constexpr int kFastTileH = 32;
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace sa

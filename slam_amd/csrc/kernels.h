@@ -1,0 +1,128 @@
+// Argument blocks of the kernels and their host-side launchers.
+#pragma once
+
+#include "common.h"
+
+namespace sa {
+
+struct ResizeArgs {
+    const uint8_t* src;
+    size_t src_frame_pitch;
+    int src_pitch, sw, sh;
+    uint8_t* dst;
+    size_t dst_frame_pitch;
+    int dst_pitch, dw, dh;
+    const int* xoff;
+    const uint16_t* xc1;
+    const int* yoff;
+    const uint16_t* yc1;
+    int lds_pitch, lds_rows;
+    int src_aligned;  // 1: src base and pitch are multiples of 4
+};
+
+struct FastArgs {
+    const uint8_t* img0;  // caller's level-0 frames
+    size_t img0_frame_pitch;
+    int img0_pitch;
+    int img0_aligned;
+    const uint8_t* pyr;   // levels >= 1 (level 0 slot unused)
+    uint8_t* smap;        // survivor map, same geometry as pyr (level 0 included)
+    unsigned* hist;       // [batch][nlevels][256]
+    PyrGeom g;
+};
+
+struct SelectArgs {
+    const unsigned* hist;
+    FrameSelect* sel;
+    int32_t* d_count;  // may be null
+    PyrGeom g;
+};
+
+struct CompactArgs {
+    const uint8_t* smap;
+    const FrameSelect* sel;
+    unsigned* rowcnt;          // [batch][total_rows]
+    slam_amd_keypoint* kp;     // [batch][capacity]
+    uint32_t* kpxy;            // [batch][capacity]  x | y << 16
+    int capacity;
+    PyrGeom g;
+};
+
+struct DescribeArgs {
+    const uint8_t* img0;
+    size_t img0_frame_pitch;
+    int img0_pitch;
+    const uint8_t* pyr;
+    const FrameSelect* sel;
+    slam_amd_keypoint* kp;
+    const uint32_t* kpxy;
+    uint8_t* desc;       // [batch][capacity][32]
+    int capacity;
+    PyrGeom g;
+};
+
+struct MatchArgs {
+    const uint8_t* qdesc;            // set 1 descriptors
+    const slam_amd_keypoint* qkp;    // set 1 keypoints (may be null when both gates are off)
+    const int32_t* d_n1;             // optional device count of set 1 (per problem)
+    int n1;                          // rows of set 1 (upper bound when d_n1 is given)
+    const uint8_t* tdesc;
+    const slam_amd_keypoint* tkp;
+    const int32_t* d_n2;
+    int n2;
+    const int32_t* ids;              // optional gather of set-1 rows
+    int n_ids;
+    const float* q_xy;               // optional query positions (2 floats per query)
+    int cap1, cap2;                  // rows between consecutive problems of a batch
+    float area;
+    int max_level;
+    int dmax;                        // largest accepted distance (floor of max_dist, <= 256)
+    unsigned* best;                  // [batch][cap1] running keys
+    int chunk;                       // train rows per split (multiple of kTrainTile)
+    // pair mode
+    const int32_t* pairs;            // [n_pairs][2] keyframe indices, or null
+    int n_per;                       // rows per keyframe
+    int qblocks;                     // query blocks per problem
+    uint32_t* pair_out;              // [n_pairs][n_per]
+};
+
+struct FinalizeArgs {
+    const unsigned* best;
+    const int32_t* d_n1;
+    int n1;
+    const int32_t* ids;
+    int n_ids;
+    int cap1;
+    int dmax;
+    slam_amd_dmatch* out;     // [batch][cap1]
+    int32_t* n_out;           // [batch]
+};
+
+struct ProjectArgs {
+    double Rt[12];
+    double K4[4];
+    double dist[5];
+    const float* xyz;
+    float* uv;
+    int n;
+};
+
+struct DupArgs {
+    const uint8_t* d1; const float* p1; int n1;
+    const uint8_t* d2; const float* p2; int n2;
+    int desc_dist; double point_dist;
+    uint8_t* flag;
+};
+
+int launch_resize(const ResizeArgs& a, int batch, hipStream_t st);
+int launch_fast(const FastArgs& a, int batch, hipStream_t st);
+int launch_select(const SelectArgs& a, int batch, hipStream_t st);
+int launch_compact(const CompactArgs& a, int batch, hipStream_t st);
+int launch_describe(const DescribeArgs& a, int batch, hipStream_t st);
+int launch_match(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st);
+int launch_match_pairs(MatchArgs a, int n_pairs, hipStream_t st);
+int launch_finalize(const FinalizeArgs& a, int batch, hipStream_t st);
+int launch_project(const ProjectArgs& a, hipStream_t st);
+int launch_duplicates(const DupArgs& a, hipStream_t st);
+
+}  // namespace sa

@@ -1,0 +1,319 @@
+// Gated brute-force Hamming matching for gfx950.
+//
+// radiusMatch with a radius that never prunes, followed by _filterMatches, is a
+// gated arg-min: per query, the train row of least Hamming distance among the
+// rows that pass the octave and window gates, ties to the lowest train index.
+// Query descriptors sit in VGPRs (Q per lane), train descriptors are staged in
+// LDS tiles and read wave-uniformly (broadcast); a distance is 8 xor + 8
+// popcount-accumulate; the running best is one unsigned minimum over the key
+// (distance << 20 | train index).  No sort and no Nq x Nt intermediate exist.
+#include "common.h"
+#include "kernels.h"
+
+namespace sa {
+
+constexpr int kMatchBlock = 256;
+constexpr int kTrainTile = 256;      // train rows per LDS tile
+constexpr unsigned kNoMatch = 0xffffffffu;
+constexpr int kIdxBits = 20;         // key = distance << 20 | train index
+
+
+__device__ __forceinline__ int hamming256(const uint32_t (&q)[8], const uint4& a, const uint4& b) {
+    int d = __builtin_popcount(q[0] ^ a.x);
+    d += __builtin_popcount(q[1] ^ a.y);
+    d += __builtin_popcount(q[2] ^ a.z);
+    d += __builtin_popcount(q[3] ^ a.w);
+    d += __builtin_popcount(q[4] ^ b.x);
+    d += __builtin_popcount(q[5] ^ b.y);
+    d += __builtin_popcount(q[6] ^ b.z);
+    d += __builtin_popcount(q[7] ^ b.w);
+    return d;
+}
+
+// Q queries per lane; AREA / LEVEL switch the window and octave gates on.
+// PAIRS: problem = keyframe pair, one split, result stored as (d << 16 | idx).
+template <int Q, bool AREA, bool LEVEL, bool PAIRS>
+__global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
+    __shared__ uint4 s_desc[kTrainTile * 2];
+    __shared__ float s_tx[AREA ? kTrainTile : 1];
+    __shared__ float s_ty[AREA ? kTrainTile : 1];
+    __shared__ int s_toct[LEVEL ? kTrainTile : 1];
+
+    int prob, qblock, split;
+    size_t qbase, tbase;  // first row of the problem's query / train set
+    int nq, nt;
+    if (PAIRS) {
+        prob = blockIdx.x / a.qblocks;
+        qblock = blockIdx.x - prob * a.qblocks;
+        split = 0;
+        qbase = (size_t)a.pairs[2 * prob] * a.n_per;
+        tbase = (size_t)a.pairs[2 * prob + 1] * a.n_per;
+        nq = nt = a.n_per;
+    } else {
+        prob = blockIdx.z;
+        qblock = blockIdx.x;
+        split = blockIdx.y;
+        qbase = (size_t)prob * a.cap1;
+        tbase = (size_t)prob * a.cap2;
+        int n1 = a.n1, n2 = a.n2;
+        if (a.d_n1) n1 = min(n1, a.d_n1[prob]);
+        if (a.d_n2) n2 = min(n2, a.d_n2[prob]);
+        nq = a.ids ? a.n_ids : n1;
+        nt = n2;
+    }
+    const int t_begin = split * a.chunk;
+    const int t_end = PAIRS ? nt : min(nt, t_begin + a.chunk);
+    if (qblock * (kMatchBlock * Q) >= nq || t_begin >= t_end) return;
+
+    uint32_t q[Q][8];
+    float qx[Q], qy[Q];
+    bool qhigh[Q];
+    unsigned best[Q];
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        const int qi = qblock * (kMatchBlock * Q) + k * kMatchBlock + threadIdx.x;
+        best[k] = kNoMatch;
+        qx[k] = qy[k] = 0.f;
+        qhigh[k] = false;
+        if (qi < nq) {
+            const size_t row = qbase + (size_t)((!PAIRS && a.ids) ? a.ids[qi] : qi);
+            const uint4* p = reinterpret_cast<const uint4*>(a.qdesc + row * 32);
+            const uint4 lo = p[0], hi = p[1];
+            q[k][0] = lo.x; q[k][1] = lo.y; q[k][2] = lo.z; q[k][3] = lo.w;
+            q[k][4] = hi.x; q[k][5] = hi.y; q[k][6] = hi.z; q[k][7] = hi.w;
+            if (AREA) {
+                if (!PAIRS && a.q_xy) {
+                    qx[k] = a.q_xy[2 * (qbase + qi)];
+                    qy[k] = a.q_xy[2 * (qbase + qi) + 1];
+                } else {
+                    qx[k] = a.qkp[row].x;
+                    qy[k] = a.qkp[row].y;
+                }
+            }
+            if (LEVEL) qhigh[k] = a.qkp[row].octave > a.max_level;
+        } else {
+#pragma unroll
+            for (int w = 0; w < 8; w++) q[k][w] = 0;
+        }
+    }
+
+    for (int t0 = t_begin; t0 < t_end; t0 += kTrainTile) {
+        const int tn = min(kTrainTile, t_end - t0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < tn * 2; i += kMatchBlock)
+            s_desc[i] = reinterpret_cast<const uint4*>(a.tdesc + (tbase + t0) * 32)[i];
+        if (AREA || LEVEL) {
+            for (int i = threadIdx.x; i < tn; i += kMatchBlock) {
+                const slam_amd_keypoint& kp = a.tkp[tbase + t0 + i];
+                if (AREA) { s_tx[i] = kp.x; s_ty[i] = kp.y; }
+                if (LEVEL) s_toct[i] = kp.octave;
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int j = 0; j < tn; j++) {
+            const uint4 ta = s_desc[2 * j], tb = s_desc[2 * j + 1];
+            const unsigned tidx = (unsigned)(t0 + j);
+            const bool thigh = LEVEL ? (s_toct[j] > a.max_level) : false;
+#pragma unroll
+            for (int k = 0; k < Q; k++) {
+                const int d = hamming256(q[k], ta, tb);
+                unsigned key = ((unsigned)d << kIdxBits) | tidx;
+                if (LEVEL) { if (thigh && qhigh[k]) key = kNoMatch; }
+                if (AREA) {
+                    const float dx = qx[k] - s_tx[j], dy = qy[k] - s_ty[j];
+                    if (!(fabsf(dx) < a.area && fabsf(dy) < a.area)) key = kNoMatch;
+                }
+                best[k] = min(best[k], key);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        const int qi = qblock * (kMatchBlock * Q) + k * kMatchBlock + threadIdx.x;
+        if (qi >= nq) continue;
+        if (PAIRS) {
+            unsigned out = kNoMatch;
+            if (best[k] != kNoMatch) {
+                const unsigned d = best[k] >> kIdxBits, t = best[k] & ((1u << kIdxBits) - 1);
+                if ((int)d <= a.dmax) out = (d << 16) | t;
+            }
+            a.pair_out[(size_t)prob * a.n_per + qi] = out;
+        } else {
+            if (best[k] != kNoMatch) atomicMin(&a.best[qbase + qi], best[k]);
+        }
+    }
+}
+
+// Keys -> cv::DMatch records in ascending query order, one workgroup per problem.
+
+__global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int prob = blockIdx.x;
+    int n1 = a.n1;
+    if (a.d_n1) n1 = min(n1, a.d_n1[prob]);
+    const int nq = a.ids ? a.n_ids : n1;
+    const unsigned* best = a.best + (size_t)prob * a.cap1;
+    slam_amd_dmatch* out = a.out + (size_t)prob * a.cap1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < nq; q0 += 1024) {
+        const int qi = q0 + threadIdx.x;
+        unsigned key = kNoMatch;
+        if (qi < nq) key = best[qi];
+        const unsigned d = key >> kIdxBits;
+        const bool has = key != kNoMatch && (int)d <= a.dmax;
+        const unsigned long long m = __ballot(has);
+        if (lane == 0) s_wave[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wave; w++) before += s_wave[w];
+        if (has) {
+            const int pos = before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            slam_amd_dmatch r;
+            r.queryIdx = a.ids ? a.ids[qi] : qi;
+            r.trainIdx = (int)(key & ((1u << kIdxBits) - 1));
+            r.imgIdx = 0;
+            r.distance = (float)d;
+            out[pos] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += s_wave[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.n_out[prob] = s_base;
+}
+
+// Pinhole projection with radial/tangential distortion, double arithmetic.
+
+__global__ __launch_bounds__(256) void project_kernel(ProjectArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const double X = a.xyz[3 * i], Y = a.xyz[3 * i + 1], Z = a.xyz[3 * i + 2];
+    double x = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.Rt[0], X), __dmul_rn(a.Rt[1], Y)), __dmul_rn(a.Rt[2], Z)), a.Rt[3]);
+    double y = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.Rt[4], X), __dmul_rn(a.Rt[5], Y)), __dmul_rn(a.Rt[6], Z)), a.Rt[7]);
+    double z = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.Rt[8], X), __dmul_rn(a.Rt[9], Y)), __dmul_rn(a.Rt[10], Z)), a.Rt[11]);
+    z = z != 0.0 ? __ddiv_rn(1.0, z) : 1.0;
+    x = __dmul_rn(x, z);
+    y = __dmul_rn(y, z);
+    const double r2 = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+    const double r4 = __dmul_rn(r2, r2), r6 = __dmul_rn(r4, r2);
+    const double a1 = __dmul_rn(__dmul_rn(2.0, x), y);
+    const double a2 = __dadd_rn(r2, __dmul_rn(__dmul_rn(2.0, x), x));
+    const double a3 = __dadd_rn(r2, __dmul_rn(__dmul_rn(2.0, y), y));
+    const double cd = __dadd_rn(__dadd_rn(__dadd_rn(1.0, __dmul_rn(a.dist[0], r2)), __dmul_rn(a.dist[1], r4)), __dmul_rn(a.dist[4], r6));
+    const double xd = __dadd_rn(__dadd_rn(__dmul_rn(x, cd), __dmul_rn(a.dist[2], a1)), __dmul_rn(a.dist[3], a2));
+    const double yd = __dadd_rn(__dadd_rn(__dmul_rn(y, cd), __dmul_rn(a.dist[2], a3)), __dmul_rn(a.dist[3], a1));
+    a.uv[2 * i] = (float)__dadd_rn(__dmul_rn(xd, a.K4[0]), a.K4[2]);
+    a.uv[2 * i + 1] = (float)__dadd_rn(__dmul_rn(yd, a.K4[1]), a.K4[3]);
+}
+
+// Duplicate test of every (i, j): Hamming <= desc_dist and world distance < point_dist.
+
+__global__ __launch_bounds__(256) void duplicate_kernel(DupArgs a) {
+    __shared__ uint4 s_desc[kTrainTile * 2];
+    __shared__ float s_p[kTrainTile * 3];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float px = 0, py = 0, pz = 0;
+    if (i < a.n1) {
+        const uint4* p = reinterpret_cast<const uint4*>(a.d1 + (size_t)i * 32);
+        const uint4 lo = p[0], hi = p[1];
+        q[0] = lo.x; q[1] = lo.y; q[2] = lo.z; q[3] = lo.w;
+        q[4] = hi.x; q[5] = hi.y; q[6] = hi.z; q[7] = hi.w;
+        px = a.p1[3 * i]; py = a.p1[3 * i + 1]; pz = a.p1[3 * i + 2];
+    }
+    for (int t0 = 0; t0 < a.n2; t0 += kTrainTile) {
+        const int tn = min(kTrainTile, a.n2 - t0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < tn * 2; k += 256)
+            s_desc[k] = reinterpret_cast<const uint4*>(a.d2 + (size_t)t0 * 32)[k];
+        for (int k = threadIdx.x; k < tn * 3; k += 256) s_p[k] = a.p2[(size_t)t0 * 3 + k];
+        __syncthreads();
+        if (i < a.n1) {
+            for (int j = 0; j < tn; j++) {
+                const int d = hamming256(q, s_desc[2 * j], s_desc[2 * j + 1]);
+                uint8_t dup = 0;
+                if (d <= a.desc_dist) {
+                    const double dx = (double)__fsub_rn(px, s_p[3 * j]);
+                    const double dy = (double)__fsub_rn(py, s_p[3 * j + 1]);
+                    const double dz = (double)__fsub_rn(pz, s_p[3 * j + 2]);
+                    const double s = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+                    dup = __dsqrt_rn(s) < a.point_dist;
+                }
+                a.flag[(size_t)i * a.n2 + t0 + j] = dup;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------
+template <int Q, bool PAIRS>
+static void launch_match_t(const MatchArgs& a, dim3 grid, hipStream_t st) {
+    const bool area = a.area != -1.f, level = a.max_level != -1;
+    if (area && level) hipLaunchKernelGGL((match_kernel<Q, true, true, PAIRS>), grid, dim3(kMatchBlock), 0, st, a);
+    else if (area) hipLaunchKernelGGL((match_kernel<Q, true, false, PAIRS>), grid, dim3(kMatchBlock), 0, st, a);
+    else if (level) hipLaunchKernelGGL((match_kernel<Q, false, true, PAIRS>), grid, dim3(kMatchBlock), 0, st, a);
+    else hipLaunchKernelGGL((match_kernel<Q, false, false, PAIRS>), grid, dim3(kMatchBlock), 0, st, a);
+}
+
+// nq_bound / nt_bound: host-side upper bounds used to size the grid.
+int launch_match(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st) {
+    if (nq_bound <= 0 || nt_bound <= 0 || batch <= 0) return SLAM_AMD_OK;
+    const int qblocks = div_up(nq_bound, kMatchBlock);
+    // split the train set so that the launch has a few waves per SIMD chip-wide
+    int splits = div_up(n_cu * 8, qblocks * batch);
+    const int max_splits = div_up(nt_bound, kTrainTile);
+    splits = max(1, min(splits, max_splits));
+    a.chunk = div_up(div_up(nt_bound, splits), kTrainTile) * kTrainTile;
+    splits = div_up(nt_bound, a.chunk);
+    a.qblocks = qblocks;
+    dim3 grid(qblocks, splits, batch);
+    launch_match_t<1, false>(a, grid, st);
+    SA_HIP(hipGetLastError());
+    return SLAM_AMD_OK;
+}
+
+int launch_match_pairs(MatchArgs a, int n_pairs, hipStream_t st) {
+    if (n_pairs <= 0 || a.n_per <= 0) return SLAM_AMD_OK;
+    constexpr int Q = 2;
+    a.qblocks = div_up(a.n_per, kMatchBlock * Q);
+    a.chunk = 0;
+    const long long blocks = (long long)a.qblocks * n_pairs;
+    if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match_pairs: too many pairs for one launch");
+    dim3 grid((unsigned)blocks);
+    launch_match_t<Q, true>(a, grid, st);
+    SA_HIP(hipGetLastError());
+    return SLAM_AMD_OK;
+}
+
+int launch_finalize(const FinalizeArgs& a, int batch, hipStream_t st) {
+    hipLaunchKernelGGL(finalize_matches_kernel, dim3(batch), dim3(1024), 0, st, a);
+    SA_HIP(hipGetLastError());
+    return SLAM_AMD_OK;
+}
+
+int launch_project(const ProjectArgs& a, hipStream_t st) {
+    if (a.n <= 0) return SLAM_AMD_OK;
+    hipLaunchKernelGGL(project_kernel, dim3(div_up(a.n, 256)), dim3(256), 0, st, a);
+    SA_HIP(hipGetLastError());
+    return SLAM_AMD_OK;
+}
+
+int launch_duplicates(const DupArgs& a, hipStream_t st) {
+    if (a.n1 <= 0 || a.n2 <= 0) return SLAM_AMD_OK;
+    hipLaunchKernelGGL(duplicate_kernel, dim3(div_up(a.n1, 256)), dim3(256), 0, st, a);
+    SA_HIP(hipGetLastError());
+    return SLAM_AMD_OK;
+}
+
+}  // namespace sa

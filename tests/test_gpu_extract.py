@@ -1,0 +1,49 @@
+"""GPU parity: the HIP extraction path against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(oracle, capi, img, nfeatures, **kw):
+    po = oracle.params(nfeatures=nfeatures, **kw)
+    pg = capi.orb_params(nfeatures=nfeatures, **kw)
+    h, w = img.shape
+    ex = capi.Extractor(pg, w, h, max_batch=1, max_keypoints=max(8 * nfeatures, 4096))
+    try:
+        kp_g, d_g = ex.extract(img)
+        # pyramid first: any later mismatch is then not the resize
+        for l, ref in enumerate(oracle.build_pyramid(po, img)):
+            got = ex.debug_level(0, l)
+            assert np.array_equal(got, ref), "pyramid level %d differs" % l
+    finally:
+        ex.close()
+    kp_o, d_o = oracle.detect_and_compute(po, img)
+    assert len(kp_g) == len(kp_o), (len(kp_g), len(kp_o))
+    for f in ("octave", "response", "size", "class_id"):
+        assert np.array_equal(kp_g[f], kp_o[f]), f
+    assert np.array_equal(kp_g["x"].view(np.uint32), kp_o["x"].view(np.uint32))
+    assert np.array_equal(kp_g["y"].view(np.uint32), kp_o["y"].view(np.uint32))
+    # angles: bit-exact (stated tolerance of the path: 0 ulp between GPU and oracle)
+    assert np.array_equal(kp_g["angle"].view(np.uint32), kp_o["angle"].view(np.uint32))
+    assert np.array_equal(d_g, d_o)
+    return kp_g, d_g
+
+
+def test_extract_640x480_2000(oracle, capi):
+    img = synth.scene(640, 480, 1)
+    kp, d = _compare(oracle, capi, img, 2000)
+    assert len(kp) >= 2000
+
+
+def test_extract_main_cpp_params_odd_size(oracle, capi):
+    # 1000 features as in main.cpp:100, a size whose rows are not 4-byte aligned
+    img = synth.scene(701, 463, 7)
+    _compare(oracle, capi, img, 1000)
+
+
+def test_extract_kitti_shape(oracle, capi):
+    img = synth.scene(1241, 376, 3)
+    _compare(oracle, capi, img, 4000)
