@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X ORB frontend hot path.
+
+Primary line (one JSON object on stdout, rank 0): frames/s of ORB extraction +
+brute-force Hamming matching against the previous frame at 640x480, 2000
+features, 8 levels x 1.2 -- BASELINE.json configs[1].  A step is one batch of
+frames already resident in HBM: extract the batch, then match frame i against
+frame i-1 (the first frame of a batch against the last frame of the batch
+before).  With N > 1 every rank processes its own stream of frames (weak
+scaling, no data-path collective).
+
+The same line carries:
+  roofline      the dominant kernel of the timed region, timed with HIP events
+                on the stream it runs on
+  cpu_baseline  the CPU oracle (oracle/, 1 thread) on a bounded sample, rank 0, N = 1
+  extra         keyframe-pair matching (BASELINE.json configs[3]): all pairs of
+                --pair-keyframes x 2000 descriptors sharded over the ranks, results
+                gathered to rank 0 over RCCL, in Gcmp/s
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+VALU_PEAK_GCMP = 4914.0        # 256 CU x 128 lanes/clk x 2.4 GHz / 16 VALU ops per 256-bit compare
+
+
+def pyramid_pixels(ws, hs):
+    return [int(w) * int(h) for w, h in zip(ws, hs)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="frames per step and GPU")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--nfeatures", type=int, default=2000)
+    ap.add_argument("--capacity", type=int, default=4096)
+    ap.add_argument("--pair-keyframes", type=int, default=1024)
+    ap.add_argument("--pair-desc", type=int, default=2000)
+    ap.add_argument("--pair-chunks", type=int, default=8)
+    ap.add_argument("--no-pairs", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=60)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from slam_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs a torch.distributed.run launch with that many ranks" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    W, H, NF, B, CAP = args.width, args.height, args.nfeatures, args.batch, args.capacity
+    params = capi.orb_params(nfeatures=NF)
+    ex = capi.Extractor(params, W, H, max_batch=B, max_keypoints=CAP, device=local_rank)
+    m = capi.Matcher(device=local_rank)
+    m.reserve(B * CAP)
+    ws, hs, quotas, scales = ex.levels()
+
+    # ---- inputs: a drifting sequence of one synthetic scene, resident in HBM ----
+    n_distinct = min(B, 8)
+    seq = synth.frame_sequence(W, H, n_distinct, seed=1 + rank)
+    frames = np.stack([seq[i % n_distinct] for i in range(B)])
+    d_img = torch.from_numpy(frames).to(dev)
+    KP, DM = 28, 16
+    d_kp = torch.zeros((B + 1) * CAP * KP, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B + 1) * CAP * 32, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    d_out = torch.zeros(B * CAP * DM, dtype=torch.uint8, device=dev)
+    d_nout = torch.zeros(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    kp_p, desc_p, cnt_p = d_kp.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr()
+
+    def step():
+        ex.extract_batch_async(d_img, B, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
+        m.frame_match_batch_async(B, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
+                                  cnt_p + 4, d_out, d_nout, max_dist=300.0, area=-1.0, max_level=-1,
+                                  stream=stream)
+        # the last frame of this batch is the "previous frame" of the next one
+        d_kp[:CAP * KP].copy_(d_kp[B * CAP * KP:(B + 1) * CAP * KP], non_blocking=True)
+        d_desc[:CAP * 32].copy_(d_desc[B * CAP * 32:(B + 1) * CAP * 32], non_blocking=True)
+        d_cnt[:1].copy_(d_cnt[B:B + 1], non_blocking=True)
+
+    step()  # fills slot 0
+    for _ in range(args.warmup):
+        step()
+    capi.prof_enable(args.steps * 12 + 16)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    stages = capi.prof_collect()
+    capi.prof_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    counts = d_cnt[1:].cpu().numpy()
+    nmatch = d_nout.cpu().numpy()
+    frames_per_s = world * B * args.steps / dt
+
+    # ---- latency of one frame at a time (batch 1), same context ----
+    lat_ms = None
+    if rank == 0:
+        for _ in range(3):
+            ex.extract_batch_async(d_img, 1, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
+            m.frame_match_batch_async(1, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
+                                      cnt_p + 4, d_out, d_nout, 300.0, -1.0, -1, stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 50
+        for _ in range(reps):
+            ex.extract_batch_async(d_img, 1, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
+            m.frame_match_batch_async(1, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
+                                      cnt_p + 4, d_out, d_nout, 300.0, -1.0, -1, stream)
+            torch.cuda.synchronize()
+        lat_ms = (time.perf_counter() - t1) / reps * 1e3
+
+    # ---- roofline of the dominant kernel (algorithmic bytes per launch / event time) ----
+    px = pyramid_pixels(ws, hs)
+    P, P0, Ptop = sum(px), px[0], px[-1]
+    K = float(counts.mean())
+    alg_bytes = {
+        "resize_level (all levels)": B * ((P - Ptop) + (P - P0)),
+        "fast_nms": B * P,
+        "describe": B * K * (749 + 512 + 28 + 32),
+    }
+    roofline = None
+    kernel_stages = {k: v for k, v in stages.items() if k != "memset"}
+    if kernel_stages:
+        dom = max(kernel_stages, key=lambda k: kernel_stages[k][0])
+        ms, calls = kernel_stages[dom]
+        avg_s = ms / calls * 1e-3
+        if dom in alg_bytes:
+            ach = alg_bytes[dom] / avg_s / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "avg_launch_us": round(avg_s * 1e6, 2),
+                        "algorithmic_bytes_per_launch": int(alg_bytes[dom])}
+        else:
+            # matching is bound by integer VALU throughput (xor + popcount), not HBM or MFMA
+            cmp_per_launch = float((counts.astype(np.float64) * np.roll(counts, 1)).sum())
+            ach = cmp_per_launch / avg_s / 1e9
+            roofline = {"kernel": dom, "bound": "valu", "achieved": round(ach, 2), "peak": VALU_PEAK_GCMP,
+                        "unit": "Gcmp/s", "frac": round(ach / VALU_PEAK_GCMP, 5), "traffic": None,
+                        "avg_launch_us": round(avg_s * 1e6, 2)}
+    stage_us = {k: round(v[0] / v[1] * 1e3, 2) for k, v in stages.items()}
+
+    # ---- keyframe-pair matching, sharded over ranks, gathered to rank 0 ----
+    extra = {"stage_us_per_launch": stage_us, "latency_ms_batch1": None if lat_ms is None else round(lat_ms, 4),
+             "keypoints_per_frame": round(K, 1), "matches_per_frame": round(float(nmatch.mean()), 1)}
+    if not args.no_pairs:
+        extra["pairs"] = run_pairs(args, torch, dist, capi, synth, m, dev, rank, world, barrier)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(args, synth, seq)
+
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        line = {
+            "metric": "frames/s ORB extract+match @640x480 2k feats",
+            "value": round(frames_per_s, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%dx%d synthetic frame stream, %d ORB features, 8-level 1.2 pyramid, "
+                                   "brute-force Hamming vs previous frame (gates off)" % (W, H, NF),
+                       "frames_per_step_per_gpu": B, "keypoint_capacity": CAP,
+                       "parallelism": "replicas" if world > 1 else "single"},
+            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+        }
+        print(json.dumps(line), flush=True)
+
+
+def run_pairs(args, torch, dist, capi, synth, m, dev, rank, world, barrier):
+    """All i<j pairs of n_kf keyframes x n_per descriptors, gates off (BASELINE configs[3])."""
+    from slam_amd import pairs as pairs_mod
+    n_kf, n_per = args.pair_keyframes, args.pair_desc
+    desc = synth.random_descriptors(n_kf * n_per, seed=3)
+    d_desc = torch.from_numpy(desc).to(dev)
+    pairs = pairs_mod.all_pairs(n_kf)
+    n_pairs = len(pairs)
+    pg = pairs_mod.PairGather(torch, dist, n_pairs, n_per, world, rank, dev, args.pair_chunks)
+    d_pairs = torch.from_numpy(np.ascontiguousarray(pairs[pg.lo:max(pg.hi, pg.lo + 1)])).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def compute(a, b):
+        m.match_pairs_async(d_desc, None, n_kf, n_per, d_pairs.data_ptr() + a * 8, b - a,
+                            pg.res.data_ptr() + a * n_per * 4, 300.0, -1.0, -1, stream)
+
+    pg.run(compute, limit=64)  # warm-up on a few pairs per chunk, no gather
+    barrier()
+    t0 = time.perf_counter()
+    pg.run(compute)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_cmp = float(n_pairs) * n_per * n_per
+    res = {"workload": "%d keyframes x %d descriptors, all %d pairs i<j, gates off, results gathered to rank 0"
+                       % (n_kf, n_per, n_pairs),
+           "gcmp_per_s": round(total_cmp / dt / 1e9, 1), "seconds": round(dt, 4), "n_gpus": world,
+           "scaling": "strong", "valu_peak_gcmp_per_gpu": VALU_PEAK_GCMP,
+           "valu_frac": round(total_cmp / dt / 1e9 / (VALU_PEAK_GCMP * world), 4)}
+    if rank == 0:
+        # order-independent checksum of the gathered result, comparable across N
+        out = pg.result()
+        res["checksum"] = int(out.to(torch.int64).sum().item())
+    return res
+
+
+def cpu_baseline(args, synth, seq):
+    """The CPU oracle (1 thread) on a bounded sample of the same workload."""
+    from oracle import orb_oracle as oracle
+    po = oracle.params(nfeatures=args.nfeatures)
+    n = args.cpu_frames
+    prev = oracle.detect_and_compute(po, seq[0])
+    t0 = time.perf_counter()
+    for i in range(n):
+        cur = oracle.detect_and_compute(po, seq[(i + 1) % len(seq)])
+        oracle.match_gated(prev[1], prev[0], cur[1], cur[0], 300.0, -1.0, -1)
+        prev = cur
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames of the same %dx%d / %d-feature stream: extract + brute-force match vs previous "
+                      "frame, CPU oracle (oracle/orb_oracle.c, gcc -O2, 1 thread)" %
+                      (n, args.width, args.height, args.nfeatures)}
+
+
+if __name__ == "__main__":
+    main()

@@ -222,6 +222,17 @@ int slam_amd_duplicate_pairs(slam_amd_matcher* m,
                              const uint8_t* desc2, const float* pos2, int n2,
                              int desc_dist, double point_dist, uint8_t* flag);
 
+/* ---- per-stage timing (process-wide, off by default) -------------------------
+ * With max_marks > 0 every kernel stage launched through this library is
+ * bracketed by HIP events on its own stream (up to max_marks stages recorded);
+ * 0 switches it off.  collect() waits for the recorded events, adds the elapsed
+ * milliseconds and call counts per stage into arrays of n_stages >=
+ * SLAM_AMD_PROF_STAGES entries and clears the record.  Not thread-safe. */
+#define SLAM_AMD_PROF_STAGES 10
+int slam_amd_prof_enable(int max_marks);
+int slam_amd_prof_collect(double* total_ms, int* calls, int n_stages);
+const char* slam_amd_prof_stage_name(int stage);
+
 /* ---- host-side helpers exported for tests --------------------------------- */
 
 /* cos and sin of a float angle (radians, 0 <= a <= 7) computed in double by the

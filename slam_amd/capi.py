@@ -32,8 +32,10 @@ EXPORTS = [
     "slam_amd_frame_match", "slam_amd_frame_match_async", "slam_amd_frame_match_batch_async",
     "slam_amd_match_pairs_async",
     "slam_amd_project_points", "slam_amd_project_points_async", "slam_amd_duplicate_pairs",
+    "slam_amd_prof_enable", "slam_amd_prof_collect", "slam_amd_prof_stage_name",
     "slam_amd_sincos_f32", "slam_amd_fast_atan2", "slam_amd_linear_exact_coeffs",
 ]
+PROF_STAGES = 10
 
 
 class OrbParams(C.Structure):
@@ -102,6 +104,8 @@ def lib():
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
             C.c_int, C.c_double, C.c_void_p]
         l.slam_amd_linear_exact_coeffs.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        l.slam_amd_prof_stage_name.restype = C.c_char_p
+        l.slam_amd_prof_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib = l
     return _lib
 
@@ -143,6 +147,18 @@ def linear_exact_coeffs(src, dst):
     off = np.zeros(dst, np.int32); c1 = np.zeros(dst, np.uint16)
     check(lib().slam_amd_linear_exact_coeffs(src, dst, _ptr(off), _ptr(c1)))
     return off, c1
+
+
+def prof_enable(max_marks):
+    check(lib().slam_amd_prof_enable(int(max_marks)))
+
+
+def prof_collect():
+    """{stage name: (total ms, calls)} of the stages recorded since the last collect."""
+    ms = np.zeros(PROF_STAGES, np.float64); calls = np.zeros(PROF_STAGES, np.int32)
+    check(lib().slam_amd_prof_collect(_ptr(ms), _ptr(calls), PROF_STAGES))
+    return {lib().slam_amd_prof_stage_name(i).decode(): (float(ms[i]), int(calls[i]))
+            for i in range(PROF_STAGES) if calls[i]}
 
 
 def device_count():

@@ -25,6 +25,31 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     return SLAM_AMD_ERR_HIP;
 }
 
+// ---- per-stage event timing (process-wide, off by default) ----------------------
+struct ProfState {
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // 2 per mark: begin, end
+    std::vector<int> stage;       // stage of mark i
+    size_t used = 0;              // marks begun
+};
+static ProfState g_prof;
+
+void prof_mark(int stage, bool begin, hipStream_t st) {
+    if (!g_prof.on) return;
+    if (begin) {
+        if (g_prof.used >= g_prof.stage.size()) return;  // out of slots: stop recording
+        g_prof.stage[g_prof.used] = stage;
+        (void)hipEventRecord(g_prof.ev[2 * g_prof.used], st);
+        g_prof.used++;
+    } else {
+        // the matching begin is the latest mark of this stage
+        for (size_t i = g_prof.used; i-- > 0;) {
+            if (g_prof.stage[i] == stage) { (void)hipEventRecord(g_prof.ev[2 * i + 1], st); break; }
+            if (g_prof.used - i > 4) break;
+        }
+    }
+}
+
 // ---- a device buffer that grows, never shrinks ---------------------------------
 struct DevBuf {
     void* p = nullptr;
@@ -288,8 +313,12 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
                         (batch == 1 || frame_pitch % 4 == 0);
     ex->last_img0 = d_images; ex->last_frame_pitch = frame_pitch; ex->last_row_stride = row_stride;
 
-    SA_HIP(hipMemsetAsync(ex->hist.p, 0, (size_t)batch * g.nlevels * 256 * sizeof(unsigned), st));
+    {
+        ProfScope ps(kStageMemset, st);
+        SA_HIP(hipMemsetAsync(ex->hist.p, 0, (size_t)batch * g.nlevels * 256 * sizeof(unsigned), st));
+    }
     int rc;
+    prof_mark(kStageResize, true, st);
     for (int l = 1; l < g.nlevels; l++) {
         ResizeArgs a;
         if (l == 1) {
@@ -305,22 +334,24 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
         a.lds_pitch = ex->lds_pitch[l]; a.lds_rows = ex->lds_rows[l];
         if ((rc = launch_resize(a, batch, st))) return rc;
     }
+    prof_mark(kStageResize, false, st);
     FastArgs fa;
     fa.img0 = d_images; fa.img0_frame_pitch = frame_pitch; fa.img0_pitch = row_stride; fa.img0_aligned = aligned;
     fa.pyr = ex->pyr.as<uint8_t>(); fa.smap = ex->smap.as<uint8_t>(); fa.hist = ex->hist.as<unsigned>(); fa.g = g;
-    if ((rc = launch_fast(fa, batch, st))) return rc;
+    { ProfScope ps(kStageFast, st); if ((rc = launch_fast(fa, batch, st))) return rc; }
     SelectArgs sa_;
     sa_.hist = ex->hist.as<unsigned>(); sa_.sel = ex->sel.as<FrameSelect>(); sa_.d_count = d_count; sa_.g = g;
-    if ((rc = launch_select(sa_, batch, st))) return rc;
+    { ProfScope ps(kStageSelect, st); if ((rc = launch_select(sa_, batch, st))) return rc; }
     CompactArgs ca;
     ca.smap = ex->smap.as<uint8_t>(); ca.sel = ex->sel.as<FrameSelect>(); ca.rowcnt = ex->rowcnt.as<unsigned>();
     ca.kp = d_kp; ca.kpxy = ex->kpxy.as<uint32_t>(); ca.capacity = capacity; ca.g = g;
-    if ((rc = launch_compact(ca, batch, st))) return rc;
+    { ProfScope ps(kStageCountRows, st); if ((rc = launch_count_rows(ca, batch, st))) return rc; }
+    { ProfScope ps(kStageCompactRows, st); if ((rc = launch_compact_rows(ca, batch, st))) return rc; }
     DescribeArgs da;
     da.img0 = d_images; da.img0_frame_pitch = frame_pitch; da.img0_pitch = row_stride;
     da.pyr = ex->pyr.as<uint8_t>(); da.sel = ex->sel.as<FrameSelect>(); da.kp = d_kp;
     da.kpxy = ex->kpxy.as<uint32_t>(); da.desc = d_desc; da.capacity = capacity; da.g = g;
-    if ((rc = launch_describe(da, batch, st))) return rc;
+    { ProfScope ps(kStageDescribe, st); if ((rc = launch_describe(da, batch, st))) return rc; }
     return SLAM_AMD_OK;
 }
 
@@ -455,7 +486,10 @@ static int match_common(slam_amd_matcher* m, int batch,
     const size_t rows = (size_t)batch * cap1;
     int rc = m->best.reserve(std::max(rows, (size_t)1) * sizeof(unsigned));
     if (rc) return rc;
-    SA_HIP(hipMemsetAsync(m->best.p, 0xff, std::max(rows, (size_t)1) * sizeof(unsigned), st));
+    {
+        ProfScope ps(kStageMemset, st);
+        SA_HIP(hipMemsetAsync(m->best.p, 0xff, std::max(rows, (size_t)1) * sizeof(unsigned), st));
+    }
     MatchArgs a;
     memset(&a, 0, sizeof a);
     a.qdesc = d1; a.qkp = k1; a.d_n1 = d_n1; a.n1 = n1;
@@ -463,10 +497,11 @@ static int match_common(slam_amd_matcher* m, int batch,
     a.ids = ids; a.n_ids = n_ids; a.q_xy = q_xy; a.cap1 = cap1; a.cap2 = cap2;
     a.area = area; a.max_level = max_level; a.dmax = dmax_of(max_dist);
     a.best = m->best.as<unsigned>();
-    if ((rc = launch_match(a, batch, nq, n2, m->n_cu, st))) return rc;
+    { ProfScope ps(kStageMatch, st); if ((rc = launch_match(a, batch, nq, n2, m->n_cu, st))) return rc; }
     FinalizeArgs f;
     f.best = m->best.as<unsigned>(); f.d_n1 = d_n1; f.n1 = n1; f.ids = ids; f.n_ids = n_ids;
     f.cap1 = cap1; f.dmax = a.dmax; f.out = d_out; f.n_out = d_n_out;
+    ProfScope ps(kStageFinalize, st);
     return launch_finalize(f, batch, st);
 }
 
@@ -568,6 +603,7 @@ extern "C" int slam_amd_match_pairs_async(slam_amd_matcher* m,
     a.qdesc = d_desc; a.qkp = d_kp; a.tdesc = d_desc; a.tkp = d_kp;
     a.area = area; a.max_level = max_level; a.dmax = dmax_of(max_dist);
     a.pairs = d_pairs; a.n_per = n_per; a.pair_out = d_out;
+    ProfScope ps(kStageMatchPairs, reinterpret_cast<hipStream_t>(stream));
     return launch_match_pairs(a, n_pairs, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -636,6 +672,38 @@ extern "C" int slam_amd_duplicate_pairs(slam_amd_matcher* m,
 // =============================================================================
 // General
 // =============================================================================
+extern "C" int slam_amd_prof_enable(int max_marks) {
+    if (max_marks < 0) SA_FAIL(SLAM_AMD_ERR_ARG, "max_marks < 0");
+    for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear(); g_prof.stage.clear(); g_prof.used = 0; g_prof.on = false;
+    if (max_marks == 0) return SLAM_AMD_OK;
+    g_prof.ev.resize(2 * (size_t)max_marks);
+    for (auto& e : g_prof.ev) SA_HIP(hipEventCreate(&e));
+    g_prof.stage.assign((size_t)max_marks, -1);
+    g_prof.on = true;
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_prof_collect(double* total_ms, int* calls, int n_stages) {
+    if (!total_ms || !calls || n_stages < kStageCount) SA_FAIL(SLAM_AMD_ERR_ARG, "bad argument");
+    for (int i = 0; i < n_stages; i++) { total_ms[i] = 0; calls[i] = 0; }
+    for (size_t i = 0; i < g_prof.used; i++) {
+        float ms = 0;
+        SA_HIP(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+        SA_HIP(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+        total_ms[g_prof.stage[i]] += ms;
+        calls[g_prof.stage[i]]++;
+    }
+    g_prof.used = 0;
+    return SLAM_AMD_OK;
+}
+
+extern "C" const char* slam_amd_prof_stage_name(int stage) {
+    static const char* names[kStageCount] = {"resize_level (all levels)", "fast_nms", "select_levels",
+        "count_rows", "compact_rows", "describe", "match", "finalize_matches", "match_pairs", "memset"};
+    return (stage >= 0 && stage < kStageCount) ? names[stage] : "";
+}
+
 extern "C" int slam_amd_version(void) { return SLAM_AMD_VERSION; }
 
 extern "C" const char* slam_amd_status_string(int status) {

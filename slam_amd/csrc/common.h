@@ -60,6 +60,18 @@ struct FrameSelect {
     int pad[3];
 };
 
+// Optional per-stage timing with HIP events on the stream the kernels run on.
+enum Stage {
+    kStageResize = 0, kStageFast, kStageSelect, kStageCountRows, kStageCompactRows, kStageDescribe,
+    kStageMatch, kStageFinalize, kStageMatchPairs, kStageMemset, kStageCount
+};
+void prof_mark(int stage, bool begin, hipStream_t st);
+struct ProfScope {
+    int stage; hipStream_t st;
+    ProfScope(int s, hipStream_t t) : stage(s), st(t) { prof_mark(stage, true, st); }
+    ~ProfScope() { prof_mark(stage, false, st); }
+};
+
 constexpr int kFastTileW = 64;
 constexpr int kFastTileH = 32;
 

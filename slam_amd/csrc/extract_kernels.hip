@@ -586,10 +586,15 @@ int launch_select(const SelectArgs& a, int batch, hipStream_t st) {
     return SLAM_AMD_OK;
 }
 
-int launch_compact(const CompactArgs& a, int batch, hipStream_t st) {
+int launch_count_rows(const CompactArgs& a, int batch, hipStream_t st) {
     dim3 grid(div_up(a.g.total_rows, 4), batch);
     hipLaunchKernelGGL(count_rows_kernel, grid, dim3(256), 0, st, a);
     SA_HIP(hipGetLastError());
+    return SLAM_AMD_OK;
+}
+
+int launch_compact_rows(const CompactArgs& a, int batch, hipStream_t st) {
+    dim3 grid(div_up(a.g.total_rows, 4), batch);
     hipLaunchKernelGGL(compact_rows_kernel, grid, dim3(256), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;

@@ -117,7 +117,8 @@ struct DupArgs {
 int launch_resize(const ResizeArgs& a, int batch, hipStream_t st);
 int launch_fast(const FastArgs& a, int batch, hipStream_t st);
 int launch_select(const SelectArgs& a, int batch, hipStream_t st);
-int launch_compact(const CompactArgs& a, int batch, hipStream_t st);
+int launch_count_rows(const CompactArgs& a, int batch, hipStream_t st);
+int launch_compact_rows(const CompactArgs& a, int batch, hipStream_t st);
 int launch_describe(const DescribeArgs& a, int batch, hipStream_t st);
 int launch_match(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st);
 int launch_match_pairs(MatchArgs a, int n_pairs, hipStream_t st);

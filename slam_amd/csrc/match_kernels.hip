@@ -18,16 +18,24 @@ constexpr unsigned kNoMatch = 0xffffffffu;
 constexpr int kIdxBits = 20;         // key = distance << 20 | train index
 
 
+// popcount(x) + acc in one instruction.  Written as asm because the compiler
+// otherwise splits the eight-term sum into popcounts plus separate adds.
+__device__ __forceinline__ unsigned bcnt_acc(unsigned x, unsigned acc) {
+    unsigned r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 __device__ __forceinline__ int hamming256(const uint32_t (&q)[8], const uint4& a, const uint4& b) {
-    int d = __builtin_popcount(q[0] ^ a.x);
-    d += __builtin_popcount(q[1] ^ a.y);
-    d += __builtin_popcount(q[2] ^ a.z);
-    d += __builtin_popcount(q[3] ^ a.w);
-    d += __builtin_popcount(q[4] ^ b.x);
-    d += __builtin_popcount(q[5] ^ b.y);
-    d += __builtin_popcount(q[6] ^ b.z);
-    d += __builtin_popcount(q[7] ^ b.w);
-    return d;
+    unsigned d = bcnt_acc(q[0] ^ a.x, 0u);
+    d = bcnt_acc(q[1] ^ a.y, d);
+    d = bcnt_acc(q[2] ^ a.z, d);
+    d = bcnt_acc(q[3] ^ a.w, d);
+    d = bcnt_acc(q[4] ^ b.x, d);
+    d = bcnt_acc(q[5] ^ b.y, d);
+    d = bcnt_acc(q[6] ^ b.z, d);
+    d = bcnt_acc(q[7] ^ b.w, d);
+    return (int)d;
 }
 
 // Q queries per lane; AREA / LEVEL switch the window and octave gates on.
@@ -110,22 +118,30 @@ __global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
             }
         }
         __syncthreads();
-#pragma unroll 2
-        for (int j = 0; j < tn; j++) {
+        // one train row against the Q queries of this lane
+        auto key_of = [&](int j, int k) -> unsigned {
             const uint4 ta = s_desc[2 * j], tb = s_desc[2 * j + 1];
-            const unsigned tidx = (unsigned)(t0 + j);
-            const bool thigh = LEVEL ? (s_toct[j] > a.max_level) : false;
+            const int d = hamming256(q[k], ta, tb);
+            unsigned key = ((unsigned)d << kIdxBits) | (unsigned)(t0 + j);
+            if (LEVEL) { if (qhigh[k] && s_toct[j] > a.max_level) key = kNoMatch; }
+            if (AREA) {
+                const float dx = qx[k] - s_tx[j], dy = qy[k] - s_ty[j];
+                if (!(fabsf(dx) < a.area && fabsf(dy) < a.area)) key = kNoMatch;
+            }
+            return key;
+        };
+        int j = 0;
+        // two train rows per trip: independent popcount chains and one 3-way minimum
+        for (; j + 1 < tn; j += 2) {
 #pragma unroll
             for (int k = 0; k < Q; k++) {
-                const int d = hamming256(q[k], ta, tb);
-                unsigned key = ((unsigned)d << kIdxBits) | tidx;
-                if (LEVEL) { if (thigh && qhigh[k]) key = kNoMatch; }
-                if (AREA) {
-                    const float dx = qx[k] - s_tx[j], dy = qy[k] - s_ty[j];
-                    if (!(fabsf(dx) < a.area && fabsf(dy) < a.area)) key = kNoMatch;
-                }
-                best[k] = min(best[k], key);
+                const unsigned k0 = key_of(j, k), k1 = key_of(j + 1, k);
+                best[k] = min(min(best[k], k0), k1);
             }
+        }
+        if (j < tn) {
+#pragma unroll
+            for (int k = 0; k < Q; k++) best[k] = min(best[k], key_of(j, k));
         }
     }
 
@@ -266,21 +282,30 @@ static void launch_match_t(const MatchArgs& a, dim3 grid, hipStream_t st) {
     else hipLaunchKernelGGL((match_kernel<Q, false, false, PAIRS>), grid, dim3(kMatchBlock), 0, st, a);
 }
 
-// nq_bound / nt_bound: host-side upper bounds used to size the grid.
-int launch_match(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st) {
-    if (nq_bound <= 0 || nt_bound <= 0 || batch <= 0) return SLAM_AMD_OK;
-    const int qblocks = div_up(nq_bound, kMatchBlock);
-    // split the train set so that the launch has a few waves per SIMD chip-wide
-    int splits = div_up(n_cu * 8, qblocks * batch);
+template <int Q>
+static int launch_match_q(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st) {
+    const int qblocks = div_up(nq_bound, kMatchBlock * Q);
+    // split the train set until the launch has about two workgroups per CU
+    int splits = div_up(n_cu * 2, qblocks * batch);
     const int max_splits = div_up(nt_bound, kTrainTile);
     splits = max(1, min(splits, max_splits));
     a.chunk = div_up(div_up(nt_bound, splits), kTrainTile) * kTrainTile;
     splits = div_up(nt_bound, a.chunk);
     a.qblocks = qblocks;
     dim3 grid(qblocks, splits, batch);
-    launch_match_t<1, false>(a, grid, st);
+    launch_match_t<Q, false>(a, grid, st);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
+}
+
+// nq_bound / nt_bound: host-side upper bounds used to size the grid.
+int launch_match(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st) {
+    if (nq_bound <= 0 || nt_bound <= 0 || batch <= 0) return SLAM_AMD_OK;
+    // two queries per lane once that still leaves enough workgroups to fill the chip
+    const long long work = (long long)batch * nq_bound * div_up(nt_bound, kTrainTile);
+    if (work >= (long long)n_cu * 2 * kMatchBlock * 2)
+        return launch_match_q<2>(a, batch, nq_bound, nt_bound, n_cu, st);
+    return launch_match_q<1>(a, batch, nq_bound, nt_bound, n_cu, st);
 }
 
 int launch_match_pairs(MatchArgs a, int n_pairs, hipStream_t st) {
