@@ -123,10 +123,13 @@ int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_t* d_images
                                  slam_amd_keypoint* d_kp, uint8_t* d_desc, int32_t* d_count,
                                  int capacity, void* stream);
 
-/* Device copy of the unblurred pyramid of frame b of the last batch (level l has
- * widths[l] columns; `pitch` receives its row pitch in bytes).  For tests. */
+/* Copies one level of frame `frame` of the last batch to the host (widths[l]
+ * columns, heights[l] rows, host_stride bytes per row): the unblurred pyramid
+ * level, or the 7x7-blurred level the descriptors are sampled from.  For tests. */
 int slam_amd_extractor_debug_level(slam_amd_extractor* ex, int frame, int level,
                                    uint8_t* host_out, int host_stride);
+int slam_amd_extractor_debug_blurred_level(slam_amd_extractor* ex, int frame, int level,
+                                           uint8_t* host_out, int host_stride);
 
 /* ---- matching: replaces cv::BFMatcher::radiusMatch + _filterMatches ------
  * reference: slam::Matcher::frameMatch, src/frame/matcher.cpp:15-55 and

@@ -96,7 +96,7 @@ struct slam_amd_extractor {
     const int* yoff[kMaxLevels] = {};
     const uint16_t* yc1[kMaxLevels] = {};
     int lds_pitch[kMaxLevels] = {}, lds_rows[kMaxLevels] = {};
-    DevBuf pyr, smap, hist, rowcnt, sel, kpxy;
+    DevBuf pyr, smap, blur, hist, rowcnt, sel, kpxy;
     // host-call staging
     DevBuf h_img, h_kp, h_desc, h_count;
     int h_img_pitch = 0;
@@ -259,6 +259,7 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
     const size_t B = (size_t)max_batch;
     if ((rc = ex->pyr.reserve(B * g.frame_bytes))) return fail(rc);
     if ((rc = ex->smap.reserve(B * g.frame_bytes))) return fail(rc);
+    if ((rc = ex->blur.reserve(B * g.frame_bytes))) return fail(rc);
     if ((rc = ex->hist.reserve(B * g.nlevels * 256 * sizeof(unsigned)))) return fail(rc);
     if ((rc = ex->rowcnt.reserve(B * g.total_rows * sizeof(unsigned)))) return fail(rc);
     if ((rc = ex->sel.reserve(B * sizeof(FrameSelect)))) return fail(rc);
@@ -273,7 +274,7 @@ extern "C" int slam_amd_extractor_destroy(slam_amd_extractor* ex) {
     if (!ex) return SLAM_AMD_OK;
     (void)hipSetDevice(ex->device);
     if (ex->stream) { (void)hipStreamSynchronize(ex->stream); (void)hipStreamDestroy(ex->stream); }
-    for (DevBuf* b : {&ex->tables, &ex->pyr, &ex->smap, &ex->hist, &ex->rowcnt, &ex->sel, &ex->kpxy,
+    for (DevBuf* b : {&ex->tables, &ex->pyr, &ex->smap, &ex->blur, &ex->hist, &ex->rowcnt, &ex->sel, &ex->kpxy,
                       &ex->h_img, &ex->h_kp, &ex->h_desc, &ex->h_count})
         b->release();
     delete ex;
@@ -337,7 +338,7 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     prof_mark(kStageResize, false, st);
     FastArgs fa;
     fa.img0 = d_images; fa.img0_frame_pitch = frame_pitch; fa.img0_pitch = row_stride; fa.img0_aligned = aligned;
-    fa.pyr = ex->pyr.as<uint8_t>(); fa.smap = ex->smap.as<uint8_t>(); fa.hist = ex->hist.as<unsigned>(); fa.g = g;
+    fa.pyr = ex->pyr.as<uint8_t>(); fa.smap = ex->smap.as<uint8_t>(); fa.blur = ex->blur.as<uint8_t>(); fa.hist = ex->hist.as<unsigned>(); fa.g = g;
     { ProfScope ps(kStageFast, st); if ((rc = launch_fast(fa, batch, st))) return rc; }
     SelectArgs sa_;
     sa_.hist = ex->hist.as<unsigned>(); sa_.sel = ex->sel.as<FrameSelect>(); sa_.d_count = d_count; sa_.g = g;
@@ -349,7 +350,7 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     { ProfScope ps(kStageCompactRows, st); if ((rc = launch_compact_rows(ca, batch, st))) return rc; }
     DescribeArgs da;
     da.img0 = d_images; da.img0_frame_pitch = frame_pitch; da.img0_pitch = row_stride;
-    da.pyr = ex->pyr.as<uint8_t>(); da.sel = ex->sel.as<FrameSelect>(); da.kp = d_kp;
+    da.img0_aligned = aligned; da.pyr = ex->pyr.as<uint8_t>(); da.blur = ex->blur.as<uint8_t>(); da.sel = ex->sel.as<FrameSelect>(); da.kp = d_kp;
     da.kpxy = ex->kpxy.as<uint32_t>(); da.desc = d_desc; da.capacity = capacity; da.g = g;
     { ProfScope ps(kStageDescribe, st); if ((rc = launch_describe(da, batch, st))) return rc; }
     return SLAM_AMD_OK;
@@ -393,8 +394,8 @@ extern "C" int slam_amd_extract(slam_amd_extractor* ex, const uint8_t* gray, int
     return SLAM_AMD_OK;
 }
 
-extern "C" int slam_amd_extractor_debug_level(slam_amd_extractor* ex, int frame, int level,
-                                              uint8_t* host_out, int host_stride) {
+static int debug_level(slam_amd_extractor* ex, int frame, int level, bool blurred,
+                       uint8_t* host_out, int host_stride) {
     if (!ex || !host_out) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
     if (level < 0 || level >= ex->g.nlevels || frame < 0 || frame >= ex->max_batch)
         SA_FAIL(SLAM_AMD_ERR_ARG, "level or frame out of range");
@@ -402,16 +403,26 @@ extern "C" int slam_amd_extractor_debug_level(slam_amd_extractor* ex, int frame,
     if (host_stride < L.w) SA_FAIL(SLAM_AMD_ERR_ARG, "host_stride too small");
     SA_HIP(hipSetDevice(ex->device));
     SA_HIP(hipDeviceSynchronize());
-    if (level == 0) {
+    if (level == 0 && !blurred) {
         if (!ex->last_img0) SA_FAIL(SLAM_AMD_ERR_ARG, "no batch has been processed yet");
         SA_HIP(hipMemcpy2D(host_out, host_stride, ex->last_img0 + (size_t)frame * ex->last_frame_pitch,
                            ex->last_row_stride, L.w, L.h, hipMemcpyDeviceToHost));
     } else {
-        SA_HIP(hipMemcpy2D(host_out, host_stride,
-                           ex->pyr.as<uint8_t>() + (size_t)frame * ex->g.frame_bytes + L.off, L.pitch,
+        const uint8_t* base = blurred ? ex->blur.as<uint8_t>() : ex->pyr.as<uint8_t>();
+        SA_HIP(hipMemcpy2D(host_out, host_stride, base + (size_t)frame * ex->g.frame_bytes + L.off, L.pitch,
                            L.w, L.h, hipMemcpyDeviceToHost));
     }
     return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_extractor_debug_level(slam_amd_extractor* ex, int frame, int level,
+                                              uint8_t* host_out, int host_stride) {
+    return debug_level(ex, frame, level, false, host_out, host_stride);
+}
+
+extern "C" int slam_amd_extractor_debug_blurred_level(slam_amd_extractor* ex, int frame, int level,
+                                                      uint8_t* host_out, int host_stride) {
+    return debug_level(ex, frame, level, true, host_out, host_stride);
 }
 
 // =============================================================================

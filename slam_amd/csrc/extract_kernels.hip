@@ -96,17 +96,35 @@ __global__ __launch_bounds__(256) void resize_level_kernel(ResizeArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// FAST-9/16 + NMS.  A workgroup owns a 64 x 32 tile of one level of one frame.
-// Image tile with a 4-pixel halo -> LDS; corner scores for the tile plus a
-// 1-pixel halo -> LDS; then 3x3 strict-maximum suppression, border filter,
-// survivor map (score, or 0) to HBM and a 256-bin histogram of kept scores.
+// FAST-9/16 + NMS + blur.  A workgroup owns a 64 x 32 tile of one level of one
+// frame.  The image tile with a 4-pixel halo is staged in LDS (reflect-101
+// outside the image), then
+//   phase 1  every position of the tile plus a 1-pixel halo: compass test (a
+//            9-arc always covers two of the four compass points); survivors are
+//            compacted into an LDS list
+//   phase 2  full 16-pixel ring masks for the listed positions; corners are
+//            compacted into a second list
+//   phase 3  corner score for the listed corners only
+//   phase 4  3x3 strict-maximum suppression + border filter -> survivor map,
+//            256-bin histogram of kept scores; 7-tap blur row pass (packed u16)
+//   phase 5  blur column pass -> blurred level
+// The lists keep the expensive phases dense instead of divergent.
 // ---------------------------------------------------------------------------
 constexpr int kImgHalo = 4;
 constexpr int kImgPitch = kFastTileW + 2 * kImgHalo;  // 72
 constexpr int kImgRows = kFastTileH + 2 * kImgHalo;   // 40
-constexpr int kScPitch = kFastTileW + 4;              // 68 (66 used)
-constexpr int kScRows = kFastTileH + 2;               // 34
+constexpr int kScW = kFastTileW + 2;                  // 66 scored columns
+constexpr int kScRows = kFastTileH + 2;               // 34 scored rows
+constexpr int kScPitch = 72;                          // LDS column = tile column + 4
+constexpr int kScN = kScW * kScRows;                  // 2244 positions
+constexpr int kRowRows = kFastTileH + 6;              // 38 rows of the blur row pass
+constexpr int kListBytes = ((kScN * 2 + 15) / 16) * 16;
 
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
 
 __device__ __forceinline__ bool has_run9(unsigned m16) {
     unsigned m = m16 | (m16 << 16);
@@ -117,29 +135,18 @@ __device__ __forceinline__ bool has_run9(unsigned m16) {
     return (r & 0xffffu) != 0;
 }
 
-// Score of one pixel: 0 if not a corner, else max(t, best 9-arc) - 1.
-__device__ __forceinline__ int fast_score_px(const uint8_t* c, int t) {
+// v - ring[k] for the 16 ring pixels around c (LDS image tile, pitch kImgPitch).
+__device__ __forceinline__ void ring_diffs(const uint8_t* c, int (&d)[16]) {
     const int P = kImgPitch;
     const int v = c[0];
-    // compass points first: a 9-arc always covers at least two of them
-    const int d0 = v - c[3 * P], d4 = v - c[3], d8 = v - c[-3 * P], d12 = v - c[-3];
-    const int nd = (d0 > t) + (d4 > t) + (d8 > t) + (d12 > t);
-    const int nb = (d0 < -t) + (d4 < -t) + (d8 < -t) + (d12 < -t);
-    if (nd < 2 && nb < 2) return 0;
-    int d[16];
-    d[0] = d0; d[4] = d4; d[8] = d8; d[12] = d12;
-    d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
-    d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
-    d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
-    d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
-    unsigned dark = 0, bright = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        dark |= (unsigned)(d[k] > t) << k;
-        bright |= (unsigned)(d[k] < -t) << k;
-    }
-    if (!has_run9(dark) && !has_run9(bright)) return 0;
-    // sliding minimum / maximum over every arc of 9
+    d[0] = v - c[3 * P];       d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
+    d[4] = v - c[3];           d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
+    d[8] = v - c[-3 * P];      d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
+    d[12] = v - c[-3];         d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
+}
+
+// Corner score: max(t, best arc of 9 by min |difference|) - 1, via sliding min/max.
+__device__ __forceinline__ int fast_corner_score(const int (&d)[16], int t) {
     int lo2[16], hi2[16], lo4[16], hi4[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -163,10 +170,34 @@ __device__ __forceinline__ int fast_score_px(const uint8_t* c, int t) {
     return -b0 - 1;
 }
 
+// Append the flagged lanes' values to an LDS list (order within the list is free).
+__device__ __forceinline__ void list_append(bool flag, unsigned value, uint16_t* list, unsigned* counter) {
+    const unsigned long long m = __ballot(flag);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(counter, (unsigned)__builtin_popcountll(m));
+    base = __shfl(base, __builtin_ctzll(m), 64);
+    if (flag) list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)value;
+}
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ us2 as_us2(unsigned v) { return __builtin_bit_cast(us2, v); }
+__device__ __forceinline__ unsigned as_u32(us2 v) { return __builtin_bit_cast(unsigned, v); }
+
 __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     __shared__ __align__(16) uint8_t s_img[kImgRows * kImgPitch];
     __shared__ __align__(16) uint8_t s_sc[kScRows * kScPitch];
+    // lists (phases 1-3) and the blur row-pass buffer (phases 4-5) share one region
+    __shared__ __align__(16) uint8_t s_scratch[2 * kListBytes];
     __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_n[2];
+    uint16_t* s_list1 = reinterpret_cast<uint16_t*>(s_scratch);
+    uint16_t* s_list2 = reinterpret_cast<uint16_t*>(s_scratch + kListBytes);
+    unsigned* s_row = reinterpret_cast<unsigned*>(s_scratch);  // [38][32] packed u16 pairs
+    static_assert(kRowRows * kFastTileW * 2 <= 2 * kListBytes, "row-pass buffer must fit the scratch region");
+
     const int b = blockIdx.y;
     int l = 0;
     {
@@ -192,79 +223,162 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         pitch = L.pitch;
         aligned = true;
     }
-    s_hist[threadIdx.x] = 0;
-    // ---- stage image tile + halo (zero outside the image) ----
-    if (aligned) {
+    const int tid = threadIdx.x;
+    s_hist[tid] = 0;
+    if (tid < 2) s_n[tid] = 0;
+    for (int i = tid; i < kScRows * kScPitch / 4; i += 256) reinterpret_cast<unsigned*>(s_sc)[i] = 0;
+    // ---- stage image tile + halo, reflect-101 outside the image ----
+    {
         constexpr int kDw = kImgPitch / 4;  // 18 dwords per row
-        for (int i = threadIdx.x; i < kDw * kImgRows; i += 256) {
-            int r = i / kDw, c = i - r * kDw;
-            int gy = y0 - kImgHalo + r, gx = x0 - kImgHalo + 4 * c;
-            uint32_t v = 0;
-            if (gy >= 0 && gy < h && gx >= 0 && gx < w) {
-                const uint8_t* p = img + (size_t)gy * pitch + gx;
-                if (gx + 3 < w) {
-                    v = *reinterpret_cast<const uint32_t*>(p);
-                } else {
-                    for (int j = 0; j < 4; j++)
-                        if (gx + j < w) v |= (uint32_t)p[j] << (8 * j);
-                }
+        for (int i = tid; i < kDw * kImgRows; i += 256) {
+            const int r = i / kDw, c = i - r * kDw;
+            const int gy = reflect101(y0 - kImgHalo + r, h);
+            const int gx = x0 - kImgHalo + 4 * c;
+            const uint8_t* row = img + (size_t)gy * pitch;
+            uint32_t v;
+            if (aligned && gx >= 0 && gx + 3 < w) {
+                v = *reinterpret_cast<const uint32_t*>(row + gx);
+            } else {
+                v = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) v |= (uint32_t)row[reflect101(gx + j, w)] << (8 * j);
             }
             *reinterpret_cast<uint32_t*>(s_img + r * kImgPitch + 4 * c) = v;
         }
-    } else {
-        for (int i = threadIdx.x; i < kImgPitch * kImgRows; i += 256) {
-            int r = i / kImgPitch, c = i - r * kImgPitch;
-            int gy = y0 - kImgHalo + r, gx = x0 - kImgHalo + c;
-            uint8_t v = 0;
-            if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = img[(size_t)gy * pitch + gx];
-            s_img[r * kImgPitch + c] = v;
-        }
     }
     __syncthreads();
-    // ---- scores for the tile plus a 1-pixel halo ----
     const int t = a.g.fast_threshold;
-    for (int i = threadIdx.x; i < 66 * kScRows; i += 256) {
-        int r = i / 66, c = i - r * 66;
-        int gx = x0 - 1 + c, gy = y0 - 1 + r;
-        int s = 0;
-        if (gx >= 3 && gx < w - 3 && gy >= 3 && gy < h - 3)
-            s = fast_score_px(s_img + (r + 3) * kImgPitch + (c + 3), t);
-        s_sc[r * kScPitch + c] = (uint8_t)s;
+    // ---- phase 1: compass test on the tile plus a 1-pixel halo ----
+    for (int i0 = 0; i0 < kScN; i0 += 256) {
+        const int i = i0 + tid;
+        bool pass = false;
+        if (i < kScN) {
+            const int r = i / kScW, c = i - r * kScW;
+            const int gx = x0 - 1 + c, gy = y0 - 1 + r;
+            if (gx >= 3 && gx < w - 3 && gy >= 3 && gy < h - 3) {
+                const uint8_t* p = s_img + (r + 3) * kImgPitch + (c + 3);
+                const int v = p[0];
+                const int d0 = v - p[3 * kImgPitch], d4 = v - p[3], d8 = v - p[-3 * kImgPitch], d12 = v - p[-3];
+                const int nd = (d0 > t) + (d4 > t) + (d8 > t) + (d12 > t);
+                const int nb = (d0 < -t) + (d4 < -t) + (d8 < -t) + (d12 < -t);
+                pass = nd >= 2 || nb >= 2;
+            }
+        }
+        list_append(pass, (unsigned)i, s_list1, &s_n[0]);
     }
     __syncthreads();
-    // ---- NMS + border filter, 4 pixels per thread ----
+    // ---- phase 2: full ring, 9 contiguous darker or brighter ----
+    const int n1 = (int)s_n[0];
+    for (int k0 = 0; k0 < n1; k0 += 256) {
+        const int k = k0 + tid;
+        bool corner = false;
+        unsigned i = 0;
+        if (k < n1) {
+            i = s_list1[k];
+            const int r = i / kScW, c = i - r * kScW;
+            int d[16];
+            ring_diffs(s_img + (r + 3) * kImgPitch + (c + 3), d);
+            unsigned dark = 0, bright = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                dark |= (unsigned)(d[j] > t) << j;
+                bright |= (unsigned)(d[j] < -t) << j;
+            }
+            corner = has_run9(dark) || has_run9(bright);
+        }
+        list_append(corner, i, s_list2, &s_n[1]);
+    }
+    __syncthreads();
+    // ---- phase 3: score of the corners ----
+    const int n2 = (int)s_n[1];
+    for (int k = tid; k < n2; k += 256) {
+        const unsigned i = s_list2[k];
+        const int r = i / kScW, c = i - r * kScW;
+        int d[16];
+        ring_diffs(s_img + (r + 3) * kImgPitch + (c + 3), d);
+        s_sc[r * kScPitch + c + 3] = (uint8_t)fast_corner_score(d, t);
+    }
+    __syncthreads();
+    // ---- phase 4a: NMS + border filter, 4 pixels per thread ----
     uint8_t* smap = a.smap + (size_t)b * a.g.frame_bytes + L.off;
     const int edge = a.g.edge;
     const bool level_ok = (w > 2 * edge) && (h > 2 * edge);
-    const int tx = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    {
+        const int tx = tid & 15, tr = tid >> 4;
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const int ly = tr + 16 * rr;
-        const int gy = y0 + ly;
-        if (gy >= h) continue;
-        uint32_t packed = 0;
+        for (int rr = 0; rr < 2; rr++) {
+            const int ly = tr + 16 * rr;
+            const int gy = y0 + ly;
+            if (gy >= h) continue;
+            const uint8_t* q0 = s_sc + (ly + 1) * kScPitch + 4 + 4 * tx;
+            const uint32_t own = *reinterpret_cast<const uint32_t*>(q0);
+            uint32_t packed = 0;
+            if (own != 0 && level_ok && gy >= edge && gy < h - edge) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int lx = 4 * tx + j;
-            const int gx = x0 + lx;
-            const uint8_t* q = s_sc + (ly + 1) * kScPitch + (lx + 1);
-            const int s = q[0];
-            bool keep = s > 0 && level_ok && gx >= edge && gx < w - edge && gy >= edge && gy < h - edge;
-            if (keep) {
-                keep = s > q[-1] && s > q[1] && s > q[-kScPitch - 1] && s > q[-kScPitch] &&
-                       s > q[-kScPitch + 1] && s > q[kScPitch - 1] && s > q[kScPitch] &&
-                       s > q[kScPitch + 1];
+                for (int j = 0; j < 4; j++) {
+                    const int s = (own >> (8 * j)) & 255;
+                    const int gx = x0 + 4 * tx + j;
+                    if (s == 0 || gx < edge || gx >= w - edge) continue;
+                    const uint8_t* q = q0 + j;
+                    if (s > q[-1] && s > q[1] && s > q[-kScPitch - 1] && s > q[-kScPitch] &&
+                        s > q[-kScPitch + 1] && s > q[kScPitch - 1] && s > q[kScPitch] && s > q[kScPitch + 1]) {
+                        packed |= (uint32_t)s << (8 * j);
+                        atomicAdd(&s_hist[s], 1u);
+                    }
+                }
             }
-            if (keep) {
-                packed |= (uint32_t)s << (8 * j);
-                atomicAdd(&s_hist[s], 1u);
-            }
+            *reinterpret_cast<uint32_t*>(smap + (size_t)gy * L.pitch + x0 + 4 * tx) = packed;
         }
-        *reinterpret_cast<uint32_t*>(smap + (size_t)gy * L.pitch + x0 + 4 * tx) = packed;
+    }
+    // ---- phase 4b: blur row pass, rows y0-3 .. y0+34, packed 16-bit arithmetic ----
+    // (the lists are dead: every thread passed the barrier after phase 3)
+    for (int it = tid; it < kRowRows * 16; it += 256) {
+        const int r = it >> 4, g = it & 15;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(s_img + (r + 1) * kImgPitch) + g;
+        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];  // bytes 4g .. 4g+11; tap p_k = byte k+1
+        // P_k = (p_k, p_k+1) as two 16-bit lanes
+        const us2 P0 = as_us2(__builtin_amdgcn_perm(w1, w0, 0x0c020c01));
+        const us2 P1 = as_us2(__builtin_amdgcn_perm(w1, w0, 0x0c030c02));
+        const us2 P2 = as_us2(__builtin_amdgcn_perm(w1, w0, 0x0c040c03));
+        const us2 P3 = as_us2(__builtin_amdgcn_perm(w1, w0, 0x0c050c04));
+        const us2 P4 = as_us2(__builtin_amdgcn_perm(w1, w0, 0x0c060c05));
+        const us2 P5 = as_us2(__builtin_amdgcn_perm(w1, w0, 0x0c070c06));
+        const us2 P6 = as_us2(__builtin_amdgcn_perm(w2, w1, 0x0c040c03));
+        const us2 P7 = as_us2(__builtin_amdgcn_perm(w2, w1, 0x0c050c04));
+        const us2 P8 = as_us2(__builtin_amdgcn_perm(w2, w1, 0x0c060c05));
+        const us2 k18 = {18, 18}, k34 = {34, 34}, k49 = {49, 49}, k55 = {55, 55};
+        const us2 o01 = (P0 + P6) * k18 + (P1 + P5) * k34 + (P2 + P4) * k49 + P3 * k55;
+        const us2 o23 = (P2 + P8) * k18 + (P3 + P7) * k34 + (P4 + P6) * k49 + P5 * k55;
+        s_row[r * 32 + 2 * g] = as_u32(o01);
+        s_row[r * 32 + 2 * g + 1] = as_u32(o23);
     }
     __syncthreads();
-    const unsigned hv = s_hist[threadIdx.x];
-    if (hv) atomicAdd(&a.hist[((size_t)b * a.g.nlevels + l) * 256 + threadIdx.x], hv);
+    // ---- phase 5: blur column pass, 2 rows x 4 columns per thread ----
+    {
+        uint8_t* blur = a.blur + (size_t)b * a.g.frame_bytes + L.off;
+        const int cq = tid & 15, rs = tid >> 4;
+        unsigned col[8][4];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const unsigned lo = s_row[(2 * rs + r) * 32 + 2 * cq], hi = s_row[(2 * rs + r) * 32 + 2 * cq + 1];
+            col[r][0] = lo & 0xffffu; col[r][1] = lo >> 16; col[r][2] = hi & 0xffffu; col[r][3] = hi >> 16;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int gy = y0 + 2 * rs + rr;
+            if (gy >= h) break;
+            uint32_t packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned acc = 18u * (col[rr][j] + col[rr + 6][j]) + 34u * (col[rr + 1][j] + col[rr + 5][j]) +
+                                     49u * (col[rr + 2][j] + col[rr + 4][j]) + 55u * col[rr + 3][j] + 32768u;
+                packed |= min(acc >> 16, 255u) << (8 * j);
+            }
+            *reinterpret_cast<uint32_t*>(blur + (size_t)gy * L.pitch + x0 + 4 * cq) = packed;
+        }
+    }
+    const unsigned hv = s_hist[tid];
+    if (hv) atomicAdd(&a.hist[((size_t)b * a.g.nlevels + l) * 256 + tid], hv);
 }
 
 // ---------------------------------------------------------------------------
@@ -428,23 +542,16 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(CompactArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// Describe: one wavefront per keypoint.  The 43 x 43 unblurred patch around the
-// keypoint is staged in the wave's LDS slice; from it
-//   - the intensity-centroid moments over the radius-15 disc (wave reduction),
-//   - the 7x7 fixed-point Gaussian of the inner 37 x 37 (row pass, column pass),
-//   - the 256 rotated rBRIEF comparisons (4 per lane, assembled by ballot).
-// Keypoints lie >= 31 pixels from the level border, so the patch is always
-// inside the level and the blur never touches the image border.
+// Describe: one wavefront per keypoint.  Two patches are staged in the wave's
+// LDS slice with aligned 4-byte loads: 31 x 31 of the unblurred level (intensity
+// centroid over the radius-15 disc, wave reduction) and 37 x 37 of the blurred
+// level (256 rotated rBRIEF comparisons, 4 per lane, assembled by ballot; the
+// rotated pattern reaches at most 18 pixels).  Keypoints lie >= 31 pixels from
+// the level border, so both patches are inside the level.
 // ---------------------------------------------------------------------------
-constexpr int kPatchR = 21;                 // 18 (max rotated pattern reach) + 3 (blur taps)
-constexpr int kPatchD = 2 * kPatchR + 1;    // 43
-constexpr int kPatchPitch = 44;
-constexpr int kBlurR = 18;
-constexpr int kBlurD = 2 * kBlurR + 1;      // 37
-constexpr int kRowPitch = 38;               // uint16 row-pass buffer: 43 rows x 37 (+1) columns
-constexpr int kBlurPitch = 40;
-constexpr int kWaveLds = kPatchD * kPatchPitch + kPatchD * kRowPitch * 2 + kBlurD * kBlurPitch + 12;  // 6652 -> keep 4-aligned
-
+constexpr int kURad = 15, kURows = 31, kUPitch = 36;   // 31 columns + up to 3 alignment bytes
+constexpr int kBRad = 18, kBRows = 37, kBPitch = 40;   // 37 columns + up to 3 alignment bytes
+constexpr int kWaveLds = kURows * kUPitch + kBRows * kBPitch;  // 2596
 
 __constant__ int8_t c_pattern[256 * 4] = {
 #include "orb_pattern_31.inc"
@@ -452,113 +559,114 @@ __constant__ int8_t c_pattern[256 * 4] = {
 
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
+// Copies rows [y - R, y + R] x columns [x - R, x + R] of img into LDS.  Returns
+// the column shift: patch column c of row r is at dst[r * PITCH + shift + c].
+template <int R, int PITCH>
+__device__ __forceinline__ int stage_patch(const uint8_t* img, int pitch, bool aligned, int x, int y,
+                                           uint8_t* dst, int lane) {
+    constexpr int ROWS = 2 * R + 1;
+    const uint8_t* p0 = img + (size_t)(y - R) * pitch + (x - R);
+    if (aligned) {
+        const int shift = (int)(reinterpret_cast<uintptr_t>(p0) & 3);
+        constexpr int DW = PITCH / 4;
+        const uint8_t* base = p0 - shift;
+        for (int k = lane; k < ROWS * DW; k += 64) {
+            const int r = k / DW, c = k - r * DW;
+            *reinterpret_cast<uint32_t*>(dst + r * PITCH + 4 * c) =
+                *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * c);
+        }
+        return shift;
+    }
+    for (int k = lane; k < ROWS * ROWS; k += 64) {
+        const int r = k / ROWS, c = k - r * ROWS;
+        dst[r * PITCH + c] = p0[(size_t)r * pitch + c];
+    }
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
     __shared__ __align__(16) uint8_t s_all[4 * kWaveLds];
     const int b = blockIdx.y;
+    const int n = min(a.sel[b].total, a.capacity);
+    if (blockIdx.x * 4 >= n) return;  // whole workgroup beyond the last keypoint
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wave;
-    const int n = min(a.sel[b].total, a.capacity);
-    const bool active = i < n;
-    uint8_t* s_patch = s_all + wave * kWaveLds;
-    uint16_t* s_row = reinterpret_cast<uint16_t*>(s_patch + kPatchD * kPatchPitch);
-    uint8_t* s_blur = reinterpret_cast<uint8_t*>(s_row + kPatchD * kRowPitch);
+    if (i >= n) return;               // waves are independent: no workgroup barrier below
+    uint8_t* s_u = s_all + wave * kWaveLds;
+    uint8_t* s_b = s_u + kURows * kUPitch;
 
     slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity + i;
-    int x = 0, y = 0, l = 0;
-    const uint8_t* img = nullptr;
-    int pitch = 0;
-    if (active) {
-        const uint32_t xy = a.kpxy[(size_t)b * a.capacity + i];
-        x = (int)(xy & 0xffffu); y = (int)(xy >> 16);
-        l = kp->octave;
-        if (l == 0) {
-            img = a.img0 + (size_t)b * a.img0_frame_pitch;
-            pitch = a.img0_pitch;
-        } else {
-            img = a.pyr + (size_t)b * a.g.frame_bytes + a.g.lv[l].off;
-            pitch = a.g.lv[l].pitch;
-        }
-        // ---- stage the patch ----
-        const uint8_t* p0 = img + (size_t)(y - kPatchR) * pitch + (x - kPatchR);
-        for (int k = lane; k < kPatchD * kPatchD; k += 64) {
-            int r = k / kPatchD, c = k - r * kPatchD;
-            s_patch[r * kPatchPitch + c] = p0[(size_t)r * pitch + c];
-        }
+    const uint32_t xy = a.kpxy[(size_t)b * a.capacity + i];
+    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+    const int l = kp->octave;
+    const LevelGeom& L = a.g.lv[l];
+    const uint8_t* img;
+    int pitch;
+    bool aligned = true;
+    if (l == 0) {
+        img = a.img0 + (size_t)b * a.img0_frame_pitch;
+        pitch = a.img0_pitch;
+        aligned = a.img0_aligned != 0;
+    } else {
+        img = a.pyr + (size_t)b * a.g.frame_bytes + L.off;
+        pitch = L.pitch;
     }
-    __syncthreads();
-    float angle = 0.f;
-    if (active) {
-        // ---- intensity centroid: two disc rows per step (lanes 0-30 / 32-62) ----
-        const uint8_t* ctr = s_patch + kPatchR * kPatchPitch + kPatchR;
-        int m10 = 0, m01 = 0;
+    const uint8_t* blur = a.blur + (size_t)b * a.g.frame_bytes + L.off;
+    const int su = stage_patch<kURad, kUPitch>(img, pitch, aligned, x, y, s_u, lane);
+    const int sb = stage_patch<kBRad, kBPitch>(blur, L.pitch, true, x, y, s_b, lane);
+    // LDS traffic of one wave executes in order; this only keeps the compiler from
+    // moving the reads above the writes.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- intensity centroid: two disc rows per step (lanes 0-30 / 32-62) ----
+    const uint8_t* ctr = s_u + kURad * kUPitch + su + kURad;
+    int m10 = 0, m01 = 0;
+    {
         const int half = lane >> 5, u = (lane & 31) - 15;
 #pragma unroll 1
         for (int vv = 0; vv < 16; vv++) {
-            // rows: half 0 -> v = -15 + vv (v in [-15, 0]); half 1 -> v = 1 + vv (v in [1, 16))
+            // half 0: v = -15 + vv (v in [-15, 0]); half 1: v = 1 + vv (v in [1, 16], 16 unused)
             const int v = half ? (1 + vv) : (-15 + vv);
             const int av = v < 0 ? -v : v;
-            if (av <= 15 && (lane & 31) < 31) {
-                if (u >= -c_umax[av] && u <= c_umax[av]) {
-                    int val = ctr[v * kPatchPitch + u];
-                    m10 += u * val;
-                    m01 += v * val;
-                }
+            if (av <= 15 && (lane & 31) < 31 && u >= -c_umax[av] && u <= c_umax[av]) {
+                const int val = ctr[v * kUPitch + u];
+                m10 += u * val;
+                m01 += v * val;
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            m10 += __shfl_xor(m10, o, 64);
-            m01 += __shfl_xor(m01, o, 64);
-        }
-        angle = fast_atan2_deg((float)m01, (float)m10);
-        // ---- blur, row pass: 43 rows x 37 columns ----
-        for (int k = lane; k < kPatchD * kBlurD; k += 64) {
-            int r = k / kBlurD, c = k - r * kBlurD;
-            const uint8_t* q = s_patch + r * kPatchPitch + c;  // columns c .. c+6
-            unsigned acc = 18u * (q[0] + q[6]) + 34u * (q[1] + q[5]) + 49u * (q[2] + q[4]) + 55u * q[3];
-            s_row[r * kRowPitch + c] = (uint16_t)acc;
-        }
     }
-    __syncthreads();
-    if (active) {
-        // ---- blur, column pass: 37 x 37 ----
-        for (int k = lane; k < kBlurD * kBlurD; k += 64) {
-            int r = k / kBlurD, c = k - r * kBlurD;
-            const uint16_t* q = s_row + r * kRowPitch + c;  // rows r .. r+6
-            unsigned acc = 18u * (q[0] + q[6 * kRowPitch]) + 34u * (q[kRowPitch] + q[5 * kRowPitch]) +
-                           49u * (q[2 * kRowPitch] + q[4 * kRowPitch]) + 55u * q[3 * kRowPitch];
-            unsigned v = (acc + 32768u) >> 16;
-            s_blur[r * kBlurPitch + c] = (uint8_t)min(v, 255u);
-        }
-    }
-    __syncthreads();
-    if (active) {
-        // ---- rBRIEF: pair p = 64*k + lane, k = 0..3; ballot k holds bytes 8k..8k+7 ----
-        const float rad = SA_FMUL(angle, (float)(3.14159265358979323846 / 180.0));
-        float ca, sb;
-        sincos_f32(rad, &ca, &sb);
-        const uint8_t* bc = s_blur + kBlurR * kBlurPitch + kBlurR;
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(
-            a.desc + ((size_t)b * a.capacity + i) * 32);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int8_t* pp = c_pattern + (64 * k + lane) * 4;
-            const float px0 = (float)pp[0], py0 = (float)pp[1], px1 = (float)pp[2], py1 = (float)pp[3];
-            const int ix0 = SA_RINT_I(SA_FSUB(SA_FMUL(px0, ca), SA_FMUL(py0, sb)));
-            const int iy0 = SA_RINT_I(SA_FADD(SA_FMUL(px0, sb), SA_FMUL(py0, ca)));
-            const int ix1 = SA_RINT_I(SA_FSUB(SA_FMUL(px1, ca), SA_FMUL(py1, sb)));
-            const int iy1 = SA_RINT_I(SA_FADD(SA_FMUL(px1, sb), SA_FMUL(py1, ca)));
-            const int t0 = bc[iy0 * kBlurPitch + ix0];
-            const int t1 = bc[iy1 * kBlurPitch + ix1];
-            const unsigned long long bits = __ballot(t0 < t1);
-            if (lane == 0) out[k] = bits;
-        }
-        if (lane == 0) {
-            const float sc = a.g.lv[l].scale;
-            kp->angle = angle;
-            kp->x = SA_FMUL((float)x, sc);
-            kp->y = SA_FMUL((float)y, sc);
-        }
+    for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o, 64);
+        m01 += __shfl_xor(m01, o, 64);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- rBRIEF: pair p = 64*k + lane, k = 0..3; ballot k holds bytes 8k..8k+7 ----
+    const float rad = SA_FMUL(angle, (float)(3.14159265358979323846 / 180.0));
+    float ca, sb_;
+    sincos_f32(rad, &ca, &sb_);
+    const uint8_t* bc = s_b + kBRad * kBPitch + sb + kBRad;
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(a.desc + ((size_t)b * a.capacity + i) * 32);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int8_t* pp = c_pattern + (64 * k + lane) * 4;
+        const float px0 = (float)pp[0], py0 = (float)pp[1], px1 = (float)pp[2], py1 = (float)pp[3];
+        const int ix0 = SA_RINT_I(SA_FSUB(SA_FMUL(px0, ca), SA_FMUL(py0, sb_)));
+        const int iy0 = SA_RINT_I(SA_FADD(SA_FMUL(px0, sb_), SA_FMUL(py0, ca)));
+        const int ix1 = SA_RINT_I(SA_FSUB(SA_FMUL(px1, ca), SA_FMUL(py1, sb_)));
+        const int iy1 = SA_RINT_I(SA_FADD(SA_FMUL(px1, sb_), SA_FMUL(py1, ca)));
+        const int t0 = bc[iy0 * kBPitch + ix0];
+        const int t1 = bc[iy1 * kBPitch + ix1];
+        const unsigned long long bits = __ballot(t0 < t1);
+        if (lane == 0) out[k] = bits;
+    }
+    if (lane == 0) {
+        kp->angle = angle;
+        kp->x = SA_FMUL((float)x, L.scale);
+        kp->y = SA_FMUL((float)y, L.scale);
     }
 }
 

@@ -27,6 +27,7 @@ struct FastArgs {
     int img0_aligned;
     const uint8_t* pyr;   // levels >= 1 (level 0 slot unused)
     uint8_t* smap;        // survivor map, same geometry as pyr (level 0 included)
+    uint8_t* blur;        // blurred levels, same geometry as pyr (level 0 included)
     unsigned* hist;       // [batch][nlevels][256]
     PyrGeom g;
 };
@@ -52,7 +53,9 @@ struct DescribeArgs {
     const uint8_t* img0;
     size_t img0_frame_pitch;
     int img0_pitch;
+    int img0_aligned;
     const uint8_t* pyr;
+    const uint8_t* blur;
     const FrameSelect* sel;
     slam_amd_keypoint* kp;
     const uint32_t* kpxy;

@@ -285,11 +285,13 @@ static void launch_match_t(const MatchArgs& a, dim3 grid, hipStream_t st) {
 template <int Q>
 static int launch_match_q(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st) {
     const int qblocks = div_up(nq_bound, kMatchBlock * Q);
-    // split the train set until the launch has about two workgroups per CU
-    int splits = div_up(n_cu * 2, qblocks * batch);
-    const int max_splits = div_up(nt_bound, kTrainTile);
-    splits = max(1, min(splits, max_splits));
-    a.chunk = div_up(div_up(nt_bound, splits), kTrainTile) * kTrainTile;
+    // The bounds are capacities: the true counts live on the device and are often
+    // half of them, so aim for many small workgroups (those beyond the true counts
+    // exit at once) and merge the train splits with an atomic minimum.
+    constexpr int kGrain = 64;
+    int splits = div_up(n_cu * 16, qblocks * batch);
+    splits = max(1, min(splits, div_up(nt_bound, kGrain)));
+    a.chunk = div_up(div_up(nt_bound, splits), kGrain) * kGrain;
     splits = div_up(nt_bound, a.chunk);
     a.qblocks = qblocks;
     dim3 grid(qblocks, splits, batch);
@@ -302,8 +304,8 @@ static int launch_match_q(MatchArgs a, int batch, int nq_bound, int nt_bound, in
 int launch_match(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st) {
     if (nq_bound <= 0 || nt_bound <= 0 || batch <= 0) return SLAM_AMD_OK;
     // two queries per lane once that still leaves enough workgroups to fill the chip
-    const long long work = (long long)batch * nq_bound * div_up(nt_bound, kTrainTile);
-    if (work >= (long long)n_cu * 2 * kMatchBlock * 2)
+    const long long tiles = (long long)batch * div_up(nq_bound, kMatchBlock * 2) * div_up(nt_bound, kTrainTile);
+    if (tiles >= (long long)n_cu * 8)
         return launch_match_q<2>(a, batch, nq_bound, nt_bound, n_cu, st);
     return launch_match_q<1>(a, batch, nq_bound, nt_bound, n_cu, st);
 }

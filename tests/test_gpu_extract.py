@@ -18,6 +18,8 @@ def _compare(oracle, capi, img, nfeatures, **kw):
         for l, ref in enumerate(oracle.build_pyramid(po, img)):
             got = ex.debug_level(0, l)
             assert np.array_equal(got, ref), "pyramid level %d differs" % l
+            assert np.array_equal(ex.debug_level(0, l, blurred=True), oracle.gaussian_blur7(ref)), \
+                "blurred level %d differs" % l
     finally:
         ex.close()
     kp_o, d_o = oracle.detect_and_compute(po, img)
