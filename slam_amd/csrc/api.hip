@@ -241,7 +241,7 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
     *out = nullptr;
     int rc = check_orb_params(params);
     if (rc) return rc;
-    if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
+    if (width <= 0 || height <= 0 || width > 16383 || height > 16383)
         SA_FAIL(SLAM_AMD_ERR_ARG, "image size out of range");
     if (max_batch <= 0 || max_batch > 65535) SA_FAIL(SLAM_AMD_ERR_ARG, "max_batch out of range");
     if (max_keypoints <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "max_keypoints must be positive");
@@ -351,7 +351,7 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     DescribeArgs da;
     da.img0 = d_images; da.img0_frame_pitch = frame_pitch; da.img0_pitch = row_stride;
     da.img0_aligned = aligned; da.pyr = ex->pyr.as<uint8_t>(); da.blur = ex->blur.as<uint8_t>(); da.sel = ex->sel.as<FrameSelect>(); da.kp = d_kp;
-    da.kpxy = ex->kpxy.as<uint32_t>(); da.desc = d_desc; da.capacity = capacity; da.g = g;
+    da.kpxy = ex->kpxy.as<uint32_t>(); da.desc = d_desc; da.capacity = capacity; da.batch = batch; da.g = g;
     { ProfScope ps(kStageDescribe, st); if ((rc = launch_describe(da, batch, st))) return rc; }
     return SLAM_AMD_OK;
 }

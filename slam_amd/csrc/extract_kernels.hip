@@ -461,83 +461,103 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
     return v;
 }
 
+constexpr int kRowsPerWave = 1;
+
+// Number of survivors with score >= cut in every row, kRowsPerWave rows per wave.
 __global__ __launch_bounds__(256) void count_rows_kernel(CompactArgs a) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.g.total_rows) return;
-    const int l = level_of_row(a.g, row);
-    const LevelGeom& L = a.g.lv[l];
-    const int y = row - L.row_base;
-    const unsigned cut = (unsigned)a.sel[b].cut[l];
-    unsigned cnt = 0;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kRowsPerWave;
+    if (row0 >= a.g.total_rows) return;
     const int edge = a.g.edge;
-    if (cut < 256 && y >= edge && y < L.h - edge) {
-        const uint8_t* r = a.smap + (size_t)b * a.g.frame_bytes + L.off + (size_t)y * L.pitch;
-        for (int x = 4 * lane; x < L.pitch; x += 256) {
-            uint32_t v = *reinterpret_cast<const uint32_t*>(r + x);
+    unsigned cnt[kRowsPerWave];
 #pragma unroll
-            for (int j = 0; j < 4; j++) cnt += ((v >> (8 * j)) & 255u) >= cut;
+    for (int k = 0; k < kRowsPerWave; k++) {
+        cnt[k] = 0;
+        const int row = row0 + k;
+        if (row >= a.g.total_rows) continue;
+        const int l = level_of_row(a.g, row);
+        const LevelGeom& L = a.g.lv[l];
+        const int y = row - L.row_base;
+        const unsigned cut = (unsigned)a.sel[b].cut[l];
+        if (cut < 256 && y >= edge && y < L.h - edge) {
+            const uint8_t* r = a.smap + (size_t)b * a.g.frame_bytes + L.off + (size_t)y * L.pitch;
+            for (int x = 4 * lane; x < L.pitch; x += 256) {
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(r + x);
+                if (v == 0) continue;
+#pragma unroll
+                for (int j = 0; j < 4; j++) cnt[k] += ((v >> (8 * j)) & 255u) >= cut;
+            }
         }
     }
-    cnt = wave_sum(cnt);
-    if (lane == 0) a.rowcnt[(size_t)b * a.g.total_rows + row] = cnt;
+#pragma unroll
+    for (int k = 0; k < kRowsPerWave; k++) {
+        const unsigned c = wave_sum(cnt[k]);
+        if (lane == 0 && row0 + k < a.g.total_rows) a.rowcnt[(size_t)b * a.g.total_rows + row0 + k] = c;
+    }
 }
 
+// Writes the kept survivors of every row as keypoints, in raster order.
 __global__ __launch_bounds__(256) void compact_rows_kernel(CompactArgs a) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.g.total_rows) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kRowsPerWave;
+    if (row0 >= a.g.total_rows) return;
     const unsigned* rc = a.rowcnt + (size_t)b * a.g.total_rows;
-    if (rc[row] == 0) return;
-    const int l = level_of_row(a.g, row);
-    const LevelGeom& L = a.g.lv[l];
-    const int y = row - L.row_base;
-    const unsigned cut = (unsigned)a.sel[b].cut[l];
-    // keypoints of earlier rows of this level
-    unsigned before = 0;
-    for (int r = lane; r < y; r += 64) before += rc[L.row_base + r];
-    before = wave_sum(before);
-    unsigned base = (unsigned)a.sel[b].offset[l] + before;
-    const uint8_t* r = a.smap + (size_t)b * a.g.frame_bytes + L.off + (size_t)y * L.pitch;
     slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity;
     uint32_t* kpxy = a.kpxy + (size_t)b * a.capacity;
-    for (int xb = 0; xb < L.pitch; xb += 256) {
-        const int x = xb + 4 * lane;
-        uint32_t v = 0;
-        if (x < L.pitch) v = *reinterpret_cast<const uint32_t*>(r + x);
-        unsigned c = 0;
+#pragma unroll 1
+    for (int k = 0; k < kRowsPerWave; k++) {
+        const int row = row0 + k;
+        if (row >= a.g.total_rows) break;
+        if (rc[row] == 0) continue;
+        const int l = level_of_row(a.g, row);
+        const LevelGeom& L = a.g.lv[l];
+        const int y = row - L.row_base;
+        const unsigned cut = (unsigned)a.sel[b].cut[l];
+        // keypoints of earlier rows of this level
+        unsigned before = 0;
+        for (int r = lane; r < y; r += 64) before += rc[L.row_base + r];
+        before = wave_sum(before);
+        unsigned base = (unsigned)a.sel[b].offset[l] + before;
+        const uint8_t* r = a.smap + (size_t)b * a.g.frame_bytes + L.off + (size_t)y * L.pitch;
+        for (int xb = 0; xb < L.pitch; xb += 256) {
+            const int x = xb + 4 * lane;
+            uint32_t v = 0;
+            if (x < L.pitch) v = *reinterpret_cast<const uint32_t*>(r + x);
+            unsigned c = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) c += ((v >> (8 * j)) & 255u) >= cut;
-        // exclusive prefix of c over lanes
-        unsigned inc = c;
+            for (int j = 0; j < 4; j++) c += ((v >> (8 * j)) & 255u) >= cut;
+            if (__ballot(c != 0) == 0) continue;
+            // exclusive prefix of c over lanes
+            unsigned inc = c;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            unsigned n = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += n;
-        }
-        unsigned idx = base + inc - c;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            unsigned s = (v >> (8 * j)) & 255u;
-            if (s >= cut) {
-                if (idx < (unsigned)a.capacity) {
-                    slam_amd_keypoint k;
-                    k.x = (float)(x + j);
-                    k.y = (float)y;
-                    k.size = L.size;
-                    k.angle = -1.f;
-                    k.response = (float)s;
-                    k.octave = l;
-                    k.class_id = -1;
-                    kp[idx] = k;
-                    kpxy[idx] = (uint32_t)(x + j) | ((uint32_t)y << 16);
-                }
-                idx++;
+            for (int o = 1; o < 64; o <<= 1) {
+                unsigned nn = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += nn;
             }
+            unsigned idx = base + inc - c;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned s = (v >> (8 * j)) & 255u;
+                if (s >= cut) {
+                    if (idx < (unsigned)a.capacity) {
+                        slam_amd_keypoint q;
+                        q.x = (float)(x + j);
+                        q.y = (float)y;
+                        q.size = L.size;
+                        q.angle = -1.f;
+                        q.response = (float)s;
+                        q.octave = l;
+                        q.class_id = -1;
+                        kp[idx] = q;
+                        kpxy[idx] = (uint32_t)(x + j) | ((uint32_t)y << 14) | ((uint32_t)l << 28);
+                    }
+                    idx++;
+                }
+            }
+            base += __shfl(inc, 63, 64);
         }
-        base += __shfl(inc, 63, 64);
     }
 }
 
@@ -586,19 +606,22 @@ __device__ __forceinline__ int stage_patch(const uint8_t* img, int pitch, bool a
 
 __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
     __shared__ __align__(16) uint8_t s_all[4 * kWaveLds];
-    const int b = blockIdx.y;
+    // 1-D grid, frame index fastest, so the workgroups beyond the last keypoint of
+    // every frame (they exit at once) sit at the end of the grid.
+    const int b = blockIdx.x % a.batch;
+    const int blk = blockIdx.x / a.batch;
     const int n = min(a.sel[b].total, a.capacity);
-    if (blockIdx.x * 4 >= n) return;  // whole workgroup beyond the last keypoint
+    if (blk * 4 >= n) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 4 + wave;
+    const int i = blk * 4 + wave;
     if (i >= n) return;               // waves are independent: no workgroup barrier below
     uint8_t* s_u = s_all + wave * kWaveLds;
     uint8_t* s_b = s_u + kURows * kUPitch;
 
     slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity + i;
     const uint32_t xy = a.kpxy[(size_t)b * a.capacity + i];
-    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-    const int l = kp->octave;
+    const int x = (int)(xy & 0x3fffu), y = (int)((xy >> 14) & 0x3fffu);
+    const int l = (int)(xy >> 28);
     const LevelGeom& L = a.g.lv[l];
     const uint8_t* img;
     int pitch;
@@ -695,22 +718,24 @@ int launch_select(const SelectArgs& a, int batch, hipStream_t st) {
 }
 
 int launch_count_rows(const CompactArgs& a, int batch, hipStream_t st) {
-    dim3 grid(div_up(a.g.total_rows, 4), batch);
+    dim3 grid(div_up(a.g.total_rows, 4 * kRowsPerWave), batch);
     hipLaunchKernelGGL(count_rows_kernel, grid, dim3(256), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }
 
 int launch_compact_rows(const CompactArgs& a, int batch, hipStream_t st) {
-    dim3 grid(div_up(a.g.total_rows, 4), batch);
+    dim3 grid(div_up(a.g.total_rows, 4 * kRowsPerWave), batch);
     hipLaunchKernelGGL(compact_rows_kernel, grid, dim3(256), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }
 
 int launch_describe(const DescribeArgs& a, int batch, hipStream_t st) {
-    dim3 grid(div_up(a.capacity, 4), batch);
-    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), 0, st, a);
+    DescribeArgs d = a;
+    d.batch = batch;
+    dim3 grid((unsigned)(div_up(a.capacity, 4) * batch));
+    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), 0, st, d);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }

@@ -44,7 +44,7 @@ struct CompactArgs {
     const FrameSelect* sel;
     unsigned* rowcnt;          // [batch][total_rows]
     slam_amd_keypoint* kp;     // [batch][capacity]
-    uint32_t* kpxy;            // [batch][capacity]  x | y << 16
+    uint32_t* kpxy;            // [batch][capacity]  x | y << 14 | level << 28
     int capacity;
     PyrGeom g;
 };
@@ -61,6 +61,7 @@ struct DescribeArgs {
     const uint32_t* kpxy;
     uint8_t* desc;       // [batch][capacity][32]
     int capacity;
+    int batch;
     PyrGeom g;
 };
 
@@ -86,6 +87,7 @@ struct MatchArgs {
     const int32_t* pairs;            // [n_pairs][2] keyframe indices, or null
     int n_per;                       // rows per keyframe
     int qblocks;                     // query blocks per problem
+    int splits, batch;               // train splits per problem, problems per launch
     uint32_t* pair_out;              // [n_pairs][n_per]
 };
 

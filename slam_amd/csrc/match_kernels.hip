@@ -58,9 +58,14 @@ __global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
         tbase = (size_t)a.pairs[2 * prob + 1] * a.n_per;
         nq = nt = a.n_per;
     } else {
-        prob = blockIdx.z;
-        qblock = blockIdx.x;
-        split = blockIdx.y;
+        // 1-D grid, problem index fastest: consecutive workgroups (dealt round-robin
+        // over the XCDs) carry different problems, and the query blocks beyond the
+        // true counts, which exit at once, sit at the end of the grid.
+        const int id = blockIdx.x;
+        prob = id % a.batch;
+        const int rest = id / a.batch;
+        split = rest % a.splits;
+        qblock = rest / a.splits;
         qbase = (size_t)prob * a.cap1;
         tbase = (size_t)prob * a.cap2;
         int n1 = a.n1, n2 = a.n2;
@@ -294,7 +299,11 @@ static int launch_match_q(MatchArgs a, int batch, int nq_bound, int nt_bound, in
     a.chunk = div_up(div_up(nt_bound, splits), kGrain) * kGrain;
     splits = div_up(nt_bound, a.chunk);
     a.qblocks = qblocks;
-    dim3 grid(qblocks, splits, batch);
+    a.splits = splits;
+    a.batch = batch;
+    const long long blocks = (long long)qblocks * splits * batch;
+    if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match: problem too large for one launch");
+    dim3 grid((unsigned)blocks);
     launch_match_t<Q, false>(a, grid, st);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;

@@ -1,0 +1,495 @@
+"""Known-answer and cross-check tests of the CPU oracle (no GPU).
+
+The reference holds no tests or golden vectors for this path and OpenCV is not
+installed, so the oracle is pinned by what can be derived by hand or recomputed
+independently in numpy: Hamming distances, FAST on synthetic corners, moments of
+ramps, the resize / blur fixed-point formulas, pyramid geometry, gate semantics
+read from src/frame/matcher.cpp.  (Parity with a real OpenCV build: unpinned.)
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+UMAX = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3),
+        (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+# ---------------------------------------------------------------- geometry ----
+def test_pyramid_sizes_and_quotas(oracle):
+    cases = {
+        (640, 480, 2000): ([640, 533, 444, 370, 309, 257, 214, 179], [480, 400, 333, 278, 231, 193, 161, 134],
+                           [434, 362, 302, 251, 209, 175, 145, 122]),
+        (1241, 376, 4000): ([1241, 1034, 862, 718, 598, 499, 416, 346], [376, 313, 261, 218, 181, 151, 126, 105],
+                            [869, 724, 603, 503, 419, 349, 291, 242]),
+        (3840, 2160, 10000): ([3840, 3200, 2667, 2222, 1852, 1543, 1286, 1072],
+                              [2160, 1800, 1500, 1250, 1042, 868, 723, 603],
+                              [2172, 1810, 1508, 1257, 1047, 873, 727, 606]),
+        (1080, 720, 1000): ([1080, 900, 750, 625, 521, 434, 362, 301], [720, 600, 500, 417, 347, 289, 241, 201],
+                            [217, 181, 151, 126, 105, 87, 73, 60]),
+    }
+    for (w, h, n), (ws, hs, qs) in cases.items():
+        p = oracle.params(nfeatures=n)
+        gw, gh = oracle.pyramid_sizes(p, w, h)
+        assert list(gw) == ws and list(gh) == hs
+        q = oracle.level_quotas(p)
+        assert list(q) == qs and q.sum() == n
+
+
+def test_level_scale_is_float_pow(oracle):
+    p = oracle.params()
+    for l in range(8):
+        assert oracle.level_scale(p, l) == np.float32(np.float64(np.float32(1.2)) ** l)
+
+
+def test_frame_scale_tables(oracle):
+    # src/frame/frame.cpp:28-37
+    s, g, i = oracle.frame_scale_tables(1.2, 8)
+    exp = [np.float32(1)]
+    for k in range(1, 8):
+        exp.append(np.float32(exp[-1] * np.float32(1.2)))
+    assert list(s) == exp
+    assert all(g[k] == np.float32(exp[k] * exp[k]) for k in range(8))
+    assert all(i[k] == np.float32(np.float32(1) / g[k]) for k in range(8))
+
+
+def test_pattern_table(oracle):
+    def load(path):
+        vals = []
+        for line in open(path):
+            line = line.strip()
+            if not line or line.startswith("/*") or line.startswith("*"):
+                continue
+            vals += [int(v) for v in line.rstrip(",").split(",")]
+        return vals
+    a = load(os.path.join(HERE, "..", "oracle", "orb_pattern_31.inc"))
+    b = load(os.path.join(HERE, "..", "slam_amd", "csrc", "orb_pattern_31.inc"))
+    assert a == b, "oracle and library pattern tables differ"
+    assert len(a) == 1024
+    rows = [tuple(a[4 * i:4 * i + 4]) for i in range(256)]
+    assert len(set(rows)) == 256
+    assert min(a) == -13 and max(a) == 12
+    assert rows[0] == (8, -3, 9, 5) and rows[-1] == (-1, -6, 0, -11)
+    # every rotated sample must stay inside the 37 x 37 patch the kernel stages
+    assert max(math.hypot(r[0], r[1]) for r in rows) < 18.5
+    assert max(math.hypot(r[2], r[3]) for r in rows) < 18.5
+
+
+# ----------------------------------------------------------------- hamming ----
+def test_hamming_kat(oracle):
+    z = np.zeros(32, np.uint8)
+    o = np.full(32, 255, np.uint8)
+    assert oracle.hamming256(z, z) == 0
+    assert oracle.hamming256(z, o) == 256
+    one = z.copy(); one[17] = 0x10
+    assert oracle.hamming256(z, one) == 1
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        a = rng.integers(0, 256, 32, dtype=np.uint8); b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert oracle.hamming256(a, b) == int(np.unpackbits(a ^ b).sum())
+
+
+# -------------------------------------------------------------------- FAST ----
+def test_fast_single_bright_pixel(oracle):
+    img = np.full((21, 21), 50, np.uint8)
+    img[10, 10] = 130
+    s = oracle.fast_score_map(img, 20)
+    assert s[10, 10] == 130 - 50 - 1       # all 16 ring pixels darker by 80
+    s[10, 10] = 0
+    assert not s.any()                      # ring neighbours see one bright pixel only
+    kp = oracle.fast_detect(img, 20)
+    assert kp.tolist() == [[10, 10, 79]]
+
+
+def test_fast_threshold_boundary(oracle):
+    img = np.full((15, 15), 100, np.uint8)
+    img[7, 7] = 120                         # difference == threshold: not a corner (strict >)
+    assert not oracle.fast_score_map(img, 20).any()
+    img[7, 7] = 121
+    assert oracle.fast_score_map(img, 20)[7, 7] == 20
+
+
+def test_fast_step_edge_has_no_corner(oracle):
+    img = np.full((40, 40), 30, np.uint8)
+    img[:, 20:] = 200
+    assert not oracle.fast_score_map(img, 20).any()
+
+
+def test_fast_right_angle_corner(oracle):
+    img = np.full((40, 40), 30, np.uint8)
+    img[20:, 20:] = 200
+    s = oracle.fast_score_map(img, 20)
+    assert s[20, 20] == 200 - 30 - 1               # 11 contiguous darker ring pixels at the vertex
+    ys, xs = np.nonzero(s)
+    assert len(ys) >= 1 and all(abs(x - 20) <= 2 and abs(y - 20) <= 2 for x, y in zip(xs, ys))
+    # a perfect synthetic corner gives equal scores on neighbouring pixels, and the
+    # strict 3x3 maximum then keeps none of them; a graded corner keeps exactly one
+    assert len(oracle.fast_detect(img, 20)) == 0
+    img[20, 20] = 230
+    assert oracle.fast_detect(img, 20).tolist() == [[20, 20, 199]]
+
+
+def test_fast_score_is_largest_threshold(oracle):
+    # the score is the largest t for which the pixel is still a corner
+    img = synth.scene(96, 80, 5)
+    s20 = oracle.fast_score_map(img, 20)
+    ys, xs = np.nonzero(s20)
+    assert len(ys) > 20
+    for y, x in list(zip(ys, xs))[:40]:
+        sc = int(s20[y, x])
+        assert oracle.fast_score_map(img, sc)[y, x] > 0
+        assert oracle.fast_score_map(img, sc + 1)[y, x] == 0
+
+
+def test_fast_matches_direct_definition(oracle):
+    img = synth.scene(80, 64, 9).astype(np.int32)
+    s = oracle.fast_score_map(img.astype(np.uint8), 20)
+    h, w = img.shape
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            d = [img[y, x] - img[y + dy, x + dx] for dx, dy in RING]
+            best = 0
+            for k in range(16):
+                arc = [d[(k + j) % 16] for j in range(9)]
+                best = max(best, min(arc), -max(arc))
+            exp = best - 1 if best > 20 else 0
+            assert s[y, x] == exp, (x, y)
+
+
+def test_fast_nms_is_strict(oracle):
+    # two identical isolated corners next to each other suppress each other
+    img = np.full((21, 24), 50, np.uint8)
+    img[10, 10] = 130
+    img[10, 11] = 130
+    s = oracle.fast_score_map(img, 20)
+    if s[10, 10] and s[10, 10] == s[10, 11]:
+        assert len(oracle.fast_detect(img, 20)) == 0
+    far = np.full((21, 40), 50, np.uint8)
+    far[10, 10] = 130; far[10, 30] = 140
+    assert oracle.fast_detect(far, 20).tolist() == [[10, 10, 79], [30, 10, 89]]
+
+
+# ------------------------------------------------------------- orientation ----
+def _disc_moments(img, x, y):
+    m10 = m01 = 0
+    for v in range(-15, 16):
+        for u in range(-UMAX[abs(v)], UMAX[abs(v)] + 1):
+            m10 += u * int(img[y + v, x + u]); m01 += v * int(img[y + v, x + u])
+    return m01, m10
+
+
+def test_ic_moments_ramps(oracle):
+    xs = np.arange(64)
+    ramp_x = np.tile((2 * xs + 10).astype(np.uint8), (64, 1))
+    ramp_y = ramp_x.T.copy()
+    su2 = sum(u * u for v in range(-15, 16) for u in range(-UMAX[abs(v)], UMAX[abs(v)] + 1))
+    assert sum(2 * UMAX[abs(v)] + 1 for v in range(-15, 16)) == 749
+    m01, m10 = oracle.ic_moments(ramp_x, 32, 32)
+    assert (m01, m10) == (0, 2 * su2)
+    assert oracle.fast_atan2(m01, m10) == 0.0
+    m01, m10 = oracle.ic_moments(ramp_y, 32, 32)
+    assert m10 == 0 and m01 > 0
+    assert oracle.fast_atan2(m01, m10) == 90.0
+    img = synth.scene(100, 90, 4)
+    for (x, y) in [(40, 40), (31, 33), (68, 58)]:
+        assert oracle.ic_moments(img, x, y) == _disc_moments(img, x, y)
+
+
+def test_fast_atan2(oracle):
+    assert oracle.fast_atan2(0, 0) == 0.0
+    assert oracle.fast_atan2(0, 5) == 0.0
+    assert oracle.fast_atan2(5, 0) == 90.0
+    assert oracle.fast_atan2(0, -5) == 180.0
+    assert oracle.fast_atan2(-5, 0) == 270.0
+    rng = np.random.default_rng(1)
+    for _ in range(2000):
+        y, x = rng.integers(-200000, 200000, 2)
+        if x == 0 and y == 0:
+            continue
+        a = oracle.fast_atan2(y, x)
+        ref = math.degrees(math.atan2(y, x)) % 360.0
+        err = abs(a - ref)
+        assert min(err, 360 - err) < 0.3
+        assert 0.0 <= a <= 360.0
+
+
+# ------------------------------------------------------------------ resize ----
+def _resize_numpy(img, dw, dh, oracle):
+    sh, sw = img.shape
+    xo, xc = oracle.linear_exact_coeffs(sw, dw)
+    yo, yc = oracle.linear_exact_coeffs(sh, dh)
+    f = img.astype(np.int64)
+    x1 = np.minimum(xo + 1, sw - 1); y1 = np.minimum(yo + 1, sh - 1)
+    c1 = xc.astype(np.int64); c0 = 256 - c1
+    hrow = f[:, xo] * c0 + f[:, x1] * c1
+    m1 = yc.astype(np.int64)[:, None]; m0 = 256 - m1
+    return ((hrow[yo] * m0 + hrow[y1] * m1 + 32768) >> 16).astype(np.uint8)
+
+
+def test_resize_linear_exact(oracle):
+    img = synth.scene(121, 97, 2)
+    assert np.array_equal(oracle.resize_linear_exact(img, 121, 97), img)          # identity
+    flat = np.full((50, 70), 137, np.uint8)
+    assert (oracle.resize_linear_exact(flat, 58, 42) == 137).all()                 # constants survive
+    for (dw, dh) in [(101, 81), (100, 80), (64, 33), (150, 120)]:
+        assert np.array_equal(oracle.resize_linear_exact(img, dw, dh), _resize_numpy(img, dw, dh, oracle))
+    even = synth.scene(64, 48, 3)
+    half = oracle.resize_linear_exact(even, 32, 24)                                # exact half: 2x2 mean
+    e = even.astype(np.int32)
+    ref = (e[0::2, 0::2] + e[0::2, 1::2] + e[1::2, 0::2] + e[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(half, ref.astype(np.uint8))
+
+
+def test_linear_exact_coeffs_properties(oracle):
+    for src, dst in [(640, 533), (533, 444), (480, 400), (179, 149), (100, 100), (7, 3), (3840, 3200)]:
+        off, c1 = oracle.linear_exact_coeffs(src, dst)
+        assert (np.diff(off) >= 0).all() and off.min() >= 0 and off.max() <= src - 1
+        assert c1.max() <= 256
+        scale = 1.0 / (dst / src)
+        f = scale * (np.arange(dst) + 0.5) - 0.5
+        inside = (np.floor(f) >= 0) & (np.floor(f) < src - 1)
+        assert np.array_equal(off[inside], np.floor(f[inside]).astype(np.int32))
+        assert np.array_equal(c1[inside], np.rint((f[inside] - np.floor(f[inside])) * 256).astype(np.uint16))
+
+
+def test_pyramid_is_chained(oracle):
+    p = oracle.params()
+    img = synth.scene(200, 160, 6)
+    lv = oracle.build_pyramid(p, img)
+    assert np.array_equal(lv[0], img)
+    for l in range(1, 8):
+        h, w = lv[l].shape
+        assert np.array_equal(lv[l], oracle.resize_linear_exact(lv[l - 1], w, h))
+
+
+# -------------------------------------------------------------------- blur ----
+def test_gaussian_blur7(oracle):
+    k = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    assert k.sum() == 257
+    img = synth.scene(45, 38, 8)
+    pad = np.pad(img.astype(np.int64), 3, mode="reflect")     # numpy "reflect" == BORDER_REFLECT_101
+    rows = sum(k[i] * pad[:, i:i + img.shape[1]] for i in range(7))
+    cols = sum(k[i] * rows[i:i + img.shape[0], :] for i in range(7))
+    ref = np.minimum((cols + 32768) >> 16, 255).astype(np.uint8)
+    assert np.array_equal(oracle.gaussian_blur7(img), ref)
+    flat = np.full((20, 20), 100, np.uint8)
+    assert (oracle.gaussian_blur7(flat) == ((100 * 257 * 257 + 32768) >> 16)).all()
+    white = np.full((20, 20), 255, np.uint8)
+    assert (oracle.gaussian_blur7(white) == 255).all()        # saturates (sum exceeds 255 << 16)
+
+
+# ------------------------------------------------------------------ rBRIEF ----
+def _brief_numpy(blurred, cx, cy, angle_deg, pattern):
+    ang = np.float32(angle_deg) * np.float32(math.pi / 180.0)
+    a = np.float32(math.cos(float(ang))); b = np.float32(math.sin(float(ang)))
+    bits = []
+    for (x0, y0, x1, y1) in pattern:
+        def sample(px, py):
+            px = np.float32(px); py = np.float32(py)
+            ix = int(np.rint(np.float32(px * a) - np.float32(py * b)))
+            iy = int(np.rint(np.float32(px * b) + np.float32(py * a)))
+            return int(blurred[cy + iy, cx + ix])
+        bits.append(1 if sample(x0, y0) < sample(x1, y1) else 0)
+    return np.packbits(np.array(bits, np.uint8), bitorder="little")
+
+
+def test_brief_descriptor(oracle):
+    vals = []
+    for line in open(os.path.join(HERE, "..", "oracle", "orb_pattern_31.inc")):
+        line = line.strip()
+        if line and not line.startswith("/*") and not line.startswith("*"):
+            vals += [int(v) for v in line.rstrip(",").split(",")]
+    pattern = [tuple(vals[4 * i:4 * i + 4]) for i in range(256)]
+    img = oracle.gaussian_blur7(synth.scene(90, 90, 11))
+    for ang in (0.0, 90.0, 33.25, 181.5, 359.99):
+        got = oracle.brief_descriptor(img, 45, 44, ang)
+        assert np.array_equal(got, _brief_numpy(img, 45, 44, ang, pattern)), ang
+
+
+# -------------------------------------------------------- detectAndCompute ----
+def test_detect_and_compute_invariants(oracle):
+    img = synth.scene(320, 240, 12)
+    p = oracle.params(nfeatures=500)
+    kps, desc = oracle.detect_and_compute(p, img)
+    ws, hs = oracle.pyramid_sizes(p, 320, 240)
+    quotas = oracle.level_quotas(p)
+    levels = oracle.build_pyramid(p, img)
+    assert len(kps) > 300 and desc.shape == (len(kps), 32)
+    key = [(int(k["octave"]), ) for k in kps]
+    assert key == sorted(key)
+    pos = 0
+    for l in range(8):
+        sel = kps[kps["octave"] == l]
+        sc = oracle.level_scale(p, l)
+        lx = np.rint(sel["x"] / np.float32(sc)).astype(int); ly = np.rint(sel["y"] / np.float32(sc)).astype(int)
+        # canonical order inside the level: (y, x) ascending
+        order = list(zip(ly.tolist(), lx.tolist()))
+        assert order == sorted(order)
+        assert ((lx >= 31) & (lx < ws[l] - 31) & (ly >= 31) & (ly < hs[l] - 31)).all()
+        assert (sel["x"] == (lx.astype(np.float32) * np.float32(sc))).all()
+        assert (sel["size"] == np.float32(31) * np.float32(sc)).all()
+        assert (sel["class_id"] == -1).all()
+        # selection: every FAST survivor inside the border with score >= the cut is kept
+        det = oracle.fast_detect(levels[l], 20)
+        inb = det[(det[:, 0] >= 31) & (det[:, 0] < ws[l] - 31) & (det[:, 1] >= 31) & (det[:, 1] < hs[l] - 31)]
+        if len(inb) > quotas[l]:
+            cut = np.sort(inb[:, 2])[::-1][quotas[l] - 1]
+            keep = inb[inb[:, 2] >= cut]
+            assert len(keep) >= quotas[l]
+        else:
+            keep = inb
+        assert len(sel) == len(keep)
+        assert np.array_equal(lx, keep[:, 0]) and np.array_equal(ly, keep[:, 1])
+        assert np.array_equal(sel["response"], keep[:, 2].astype(np.float32))
+        # angle and descriptor from their own definitions
+        blurred = oracle.gaussian_blur7(levels[l])
+        for j in range(0, len(sel), max(1, len(sel) // 5)):
+            m01, m10 = oracle.ic_moments(levels[l], int(lx[j]), int(ly[j]))
+            assert sel["angle"][j] == np.float32(oracle.fast_atan2(m01, m10))
+            assert np.array_equal(desc[pos + j], oracle.brief_descriptor(blurred, int(lx[j]), int(ly[j]),
+                                                                         float(sel["angle"][j])))
+        pos += len(sel)
+
+
+def test_detect_edge_cases(oracle):
+    p = oracle.params(nfeatures=100)
+    kps, desc = oracle.detect_and_compute(p, np.full((120, 160), 77, np.uint8))   # flat image
+    assert len(kps) == 0 and desc.shape == (0, 32)
+    kps, _ = oracle.detect_and_compute(p, synth.scene(70, 66, 3))                  # upper levels <= 62 px
+    assert (kps["octave"] == 0).all()
+    p0 = oracle.params(nfeatures=0)
+    kps, _ = oracle.detect_and_compute(p0, synth.scene(160, 120, 3))
+    assert len(kps) == 0
+
+
+def test_golden_chessboard(oracle):
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    g = np.load(os.path.join(HERE, "golden", "chessboard_orb.npz"))
+    a, b = make_golden.chessboard_pair()
+    p = oracle.params(nfeatures=1000)
+    kp_a, d_a = oracle.detect_and_compute(p, a)
+    kp_b, d_b = oracle.detect_and_compute(p, b)
+    assert kp_a.tobytes() == g["kp_a"].tobytes() and np.array_equal(d_a, g["desc_a"])
+    assert kp_b.tobytes() == g["kp_b"].tobytes() and np.array_equal(d_b, g["desc_b"])
+    m = oracle.frame_match(d_a, kp_a, d_b, kp_b, None, 300.0, -1.0, 4)
+    assert m.tobytes() == g["matches"].tobytes()
+
+
+# ---------------------------------------------------------------- matching ----
+def _random_sets(nq, nt, seed, dup=False):
+    d2 = synth.random_descriptors(nt, seed)
+    if dup:
+        d2[nt // 2:] = d2[:nt - nt // 2]          # exact duplicates: ties in distance
+    rng = np.random.default_rng(seed + 1)
+    d1 = synth.noisy_copy(d2[rng.integers(0, nt, nq)], 12, seed + 2)
+    k1 = synth.random_keypoints(nq, 200, 150, seed=seed + 3)
+    k2 = synth.random_keypoints(nt, 200, 150, seed=seed + 4)
+    return d1, k1, d2, k2
+
+
+@pytest.mark.parametrize("area,max_level", [(-1.0, -1), (-1.0, 4), (-1.0, 3), (50.0, 4), (30.0, -1), (5.0, 2)])
+def test_literal_filter_equals_gated_argmin(oracle, area, max_level):
+    d1, k1, d2, k2 = _random_sets(120, 150, 3, dup=True)
+    lit = oracle.radius_match_filter(d1, k1, d2, k2, 300.0, area, max_level)
+    fast = oracle.match_gated(d1, k1, d2, k2, 300.0, area, max_level)
+    assert lit.tobytes() == fast.tobytes()
+    assert (np.diff(lit["queryIdx"]) > 0).all() and (lit["imgIdx"] == 0).all()
+    for m in lit:                                   # every match satisfies both gates and is minimal
+        q, t = k1[m["queryIdx"]], k2[m["trainIdx"]]
+        assert not (max_level != -1 and q["octave"] > max_level and t["octave"] > max_level)
+        if area != -1:
+            assert abs(q["x"] - t["x"]) < area and abs(q["y"] - t["y"]) < area
+        assert m["distance"] == oracle.hamming256(d1[m["queryIdx"]], d2[m["trainIdx"]])
+
+
+def test_octave_gate_rejects_only_when_both_exceed(oracle):
+    # src/frame/matcher.cpp:144-148: the candidate is skipped only if BOTH octaves are above maxLevel
+    d = synth.random_descriptors(2, 1)
+    kq = synth.random_keypoints(1, seed=1); kt = synth.random_keypoints(2, seed=2)
+    kq["octave"] = 6; kt["octave"] = [7, 2]
+    dq = d[:1].copy()
+    dt = np.stack([dq[0], synth.noisy_copy(dq, 40, 3)[0]])
+    m = oracle.match_gated(dq, kq, dt, kt, 300.0, -1.0, 4)
+    assert m["trainIdx"].tolist() == [1]            # identical row skipped (both high), far row accepted
+    kq["octave"] = 1
+    m = oracle.match_gated(dq, kq, dt, kt, 300.0, -1.0, 4)
+    assert m["trainIdx"].tolist() == [0] and m["distance"].tolist() == [0.0]
+
+
+def test_window_gate_is_strict_square(oracle):
+    dq = synth.random_descriptors(1, 5); dt = np.repeat(dq, 3, axis=0)
+    kq = synth.random_keypoints(1, seed=1); kt = synth.random_keypoints(3, seed=2)
+    kq["x"], kq["y"] = 100.0, 100.0
+    kt["x"] = [150.0, 149.5, 60.0]; kt["y"] = [100.0, 149.5, 60.0]
+    m = oracle.match_gated(dq, kq, dt, kt, 300.0, 50.0, -1)
+    assert m["trainIdx"].tolist() == [1]            # |dx| == 50 fails (strict), the square corner passes
+
+
+def test_ties_and_max_distance(oracle):
+    dq = synth.random_descriptors(4, 6)
+    dt = np.concatenate([synth.noisy_copy(dq, 9, 1), dq, dq])   # rows 4..7 and 8..11 are exact copies
+    kq = synth.random_keypoints(4, seed=1); kt = synth.random_keypoints(12, seed=2)
+    m = oracle.match_gated(dq, kq, dt, kt, 300.0, -1.0, -1)
+    assert m["trainIdx"].tolist() == [4, 5, 6, 7] and (m["distance"] == 0).all()
+    far = 255 - dq[:1]                                           # complement: distance 256
+    assert len(oracle.match_gated(dq[:1], kq[:1], far, kt[:1], 255.0, -1.0, -1)) == 0
+    assert len(oracle.match_gated(dq[:1], kq[:1], far, kt[:1], 255.9, -1.0, -1)) == 0
+    assert len(oracle.match_gated(dq[:1], kq[:1], far, kt[:1], 256.0, -1.0, -1)) == 1
+    assert len(oracle.match_gated(dq[:1], kq[:1], far, kt[:1], -1.0, -1.0, -1)) == 0
+
+
+def test_frame_match_ids_and_empty(oracle):
+    d1, k1, d2, k2 = _random_sets(60, 70, 9)
+    ids = np.array([5, 3, 40, 41, 59], np.int32)
+    m = oracle.frame_match(d1, k1, d2, k2, ids, 300.0, -1.0, -1)
+    full = oracle.match_gated(d1, k1, d2, k2, 300.0, -1.0, -1)
+    assert m["queryIdx"].tolist() == ids.tolist()              # output order = id order, remapped
+    for r in m:
+        assert r["trainIdx"] == full[full["queryIdx"] == r["queryIdx"]]["trainIdx"][0]
+    assert len(oracle.match_gated(d1[:0], k1[:0], d2, k2, 300.0, -1.0, -1)) == 0
+    assert len(oracle.match_gated(d1, k1, d2[:0], k2[:0], 300.0, -1.0, -1)) == 0
+
+
+# --------------------------------------------------- projection, duplicates ----
+def test_project_points(oracle):
+    rng = np.random.default_rng(3)
+    ang = 0.2
+    R = np.array([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+    Rt = np.hstack([R, [[0.1], [-0.2], [0.5]]])
+    K4 = [963.0, 950.4, 539.5, 404.5]            # data/calibration.yaml:9-15
+    X = (rng.random((200, 3)) * [4, 3, 5] + [-2, -1.5, 2]).astype(np.float32)
+    uv = oracle.project_points(Rt, K4, None, X)
+    Xc = X.astype(np.float64) @ R.T + Rt[:, 3]
+    ref = np.stack([Xc[:, 0] / Xc[:, 2] * K4[0] + K4[2], Xc[:, 1] / Xc[:, 2] * K4[1] + K4[3]], 1)
+    assert np.allclose(uv, ref, rtol=0, atol=2e-3)
+    d5 = [0.1, -0.05, 0.001, 0.002, 0.01]
+    uvd = oracle.project_points(Rt, K4, d5, X)
+    x = Xc[:, 0] / Xc[:, 2]; y = Xc[:, 1] / Xc[:, 2]; r2 = x * x + y * y
+    cd = 1 + d5[0] * r2 + d5[1] * r2 ** 2 + d5[4] * r2 ** 3
+    xd = x * cd + d5[2] * 2 * x * y + d5[3] * (r2 + 2 * x * x)
+    yd = y * cd + d5[2] * (r2 + 2 * y * y) + d5[3] * 2 * x * y
+    assert np.allclose(uvd, np.stack([xd * K4[0] + K4[2], yd * K4[1] + K4[3]], 1), rtol=0, atol=2e-3)
+
+
+def test_duplicate_pairs(oracle):
+    # src/tracking/mapper.cpp:328-346
+    d1 = synth.random_descriptors(30, 1)
+    d2 = np.concatenate([synth.noisy_copy(d1[:10], 30, 2), synth.random_descriptors(15, 3)])
+    rng = np.random.default_rng(4)
+    p1 = rng.random((30, 3)).astype(np.float32)
+    p2 = rng.random((25, 3)).astype(np.float32)
+    p2[:5] = p1[:5] + np.float32(1e-3)
+    flag = oracle.duplicate_pairs(d1, p1, d2, p2, 100, 1e-2)
+    for i in range(30):
+        for j in range(25):
+            ham = int(np.unpackbits(d1[i] ^ d2[j]).sum())
+            dist = math.sqrt(sum(float(p1[i, k] - p2[j, k]) ** 2 for k in range(3)))
+            assert flag[i, j] == int(ham <= 100 and dist < 1e-2)
+    assert flag[:5, :5].trace() == 5
