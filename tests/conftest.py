@@ -21,6 +21,10 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def capi():
+    # PyTorch-ROCm ships its own HIP/HSA runtime with the same soname as /opt/rocm's.
+    # Whichever is loaded first serves the whole process, and torch cannot see the
+    # GPU once the system runtime is already in: load torch first.
+    import torch  # noqa: F401
     from slam_amd import capi as c
     c.lib()
     return c
