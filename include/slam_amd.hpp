@@ -1,0 +1,309 @@
+// slam_amd.hpp -- C++ host layer over the C ABI (slam_amd.h), header-only, C++17.
+//
+// It mirrors the two classes of pxl-th/slam that carry the frontend hot path,
+// with the same method names, argument meaning, defaults and result order:
+//
+//   slam::Detector  (reference: include/frame/detector.hpp:15-37, src/frame/detector.cpp)
+//   slam::Matcher   (reference: include/frame/matcher.hpp:15-117, src/frame/matcher.cpp)
+//   the per-frame tables of slam::Frame (reference: src/frame/frame.cpp:14-38)
+//
+// The classes here are written against plain views (KeyFrameView, Image8) and
+// POD records whose layouts equal cv::KeyPoint / cv::DMatch / cv::Point2f /
+// cv::Point3f, so this header builds without OpenCV.  slam_amd_opencv.hpp maps
+// the reference's exact OpenCV-typed signatures onto these classes.
+//
+// Errors: the reference has no error convention on this path (OpenCV throws
+// cv::Exception); this layer throws slam_amd::Error carrying the C status.
+// An empty image yields empty outputs, as the reference relies on at
+// src/frame/frame.cpp:24.  Calls block until results are on the host, one
+// caller thread per object.
+#ifndef SLAM_AMD_HPP
+#define SLAM_AMD_HPP
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <iterator>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "slam_amd.h"
+
+namespace slam_amd {
+
+struct Point2f { float x, y; };
+struct Point3f { float x, y, z; };
+
+// Layout of cv::KeyPoint.
+struct KeyPoint {
+    Point2f pt;
+    float size;
+    float angle;
+    float response;
+    int octave;
+    int class_id;
+};
+
+// Layout of cv::DMatch.
+struct DMatch {
+    int queryIdx, trainIdx, imgIdx;
+    float distance;
+};
+
+static_assert(sizeof(KeyPoint) == sizeof(slam_amd_keypoint) && sizeof(KeyPoint) == 28, "KeyPoint layout");
+static_assert(sizeof(DMatch) == sizeof(slam_amd_dmatch) && sizeof(DMatch) == 16, "DMatch layout");
+
+class Error : public std::runtime_error {
+public:
+    Error(int status, const std::string& what) : std::runtime_error(what), status(status) {}
+    int status;
+};
+
+inline void check(int status) {
+    if (status != SLAM_AMD_OK)
+        throw Error(status, std::string(slam_amd_status_string(status)) + ": " + slam_amd_last_error());
+}
+
+// View of an 8-bit single-channel image (cv::Mat of type CV_8UC1).
+struct Image8 {
+    const uint8_t* data = nullptr;
+    int cols = 0, rows = 0;
+    size_t step = 0;  // bytes per row
+    bool empty() const { return !data || cols <= 0 || rows <= 0; }
+};
+
+// N x 32 descriptor bytes, row-major (cv::Mat N x 32 CV_8U).
+struct Descriptors {
+    std::vector<uint8_t> bytes;
+    int rows = 0;
+    const uint8_t* row(int i) const { return bytes.data() + static_cast<size_t>(i) * 32; }
+};
+
+// ---------------------------------------------------------------------------
+// Detector: replaces cv::ORB::detectAndCompute behind slam::Detector::detect.
+// ---------------------------------------------------------------------------
+class Detector {
+public:
+    Detector() { slam_amd_default_orb_params(&params_); }
+    // reference: Detector(cv::Ptr<cv::ORB>); the ORB parameters arrive as a POD here.
+    explicit Detector(const slam_amd_orb_params& params, int device = 0) : params_(params), device_(device) {}
+    Detector(const Detector&) = delete;
+    Detector& operator=(const Detector&) = delete;
+    ~Detector() { slam_amd_extractor_destroy(ex_); }
+
+    // reference: Detector::detect(image, keypoints, descriptors), src/frame/detector.cpp:6-12.
+    // Clears and refills `keypoints`, (re)allocates `descriptors`.  KP is any
+    // 28-byte record with the layout of cv::KeyPoint.
+    template <class KP>
+    void detect(const Image8& image, std::vector<KP>& keypoints, Descriptors& descriptors) {
+        static_assert(sizeof(KP) == sizeof(slam_amd_keypoint), "keypoint record must match cv::KeyPoint");
+        keypoints.clear();
+        descriptors.bytes.clear();
+        descriptors.rows = 0;
+        if (image.empty()) return;
+        ensure(image.cols, image.rows);
+        int capacity = std::max(2 * params_.nfeatures, 1024);
+        for (;;) {
+            keypoints.resize(static_cast<size_t>(capacity));
+            descriptors.bytes.resize(static_cast<size_t>(capacity) * 32);
+            int n = 0;
+            const int rc = slam_amd_extract(ex_, image.data, image.cols, image.rows, static_cast<int>(image.step),
+                                            reinterpret_cast<slam_amd_keypoint*>(keypoints.data()),
+                                            descriptors.bytes.data(), capacity, &n);
+            if (rc == SLAM_AMD_ERR_CAPACITY && n > capacity && n <= max_keypoints_) {
+                capacity = n;  // score ties pushed the count above the guess: retry with the exact size
+                continue;
+            }
+            if (rc == SLAM_AMD_ERR_CAPACITY && n > max_keypoints_) {
+                // more ties than the context was sized for: rebuild it larger, once
+                slam_amd_extractor_destroy(ex_);
+                ex_ = nullptr;
+                max_keypoints_ = n;
+                ensure(image.cols, image.rows);
+                capacity = n;
+                continue;
+            }
+            check(rc);
+            keypoints.resize(static_cast<size_t>(n));
+            descriptors.bytes.resize(static_cast<size_t>(n) * 32);
+            descriptors.rows = n;
+            return;
+        }
+    }
+
+    // reference: include/frame/detector.hpp:35-36
+    int getLevels() const { return params_.nlevels; }
+    double getScaleFactor() const { return static_cast<double>(params_.scale_factor); }
+    const slam_amd_orb_params& params() const { return params_; }
+
+private:
+    void ensure(int w, int h) {
+        if (ex_ && w == width_ && h == height_) return;
+        slam_amd_extractor_destroy(ex_);
+        ex_ = nullptr;
+        if (max_keypoints_ == 0) max_keypoints_ = std::max(4 * params_.nfeatures, 4096);
+        check(slam_amd_extractor_create(&params_, w, h, 1, max_keypoints_, device_, &ex_));
+        width_ = w;
+        height_ = h;
+    }
+    slam_amd_orb_params params_;
+    int device_ = 0;
+    slam_amd_extractor* ex_ = nullptr;
+    int width_ = 0, height_ = 0, max_keypoints_ = 0;
+};
+
+// ---------------------------------------------------------------------------
+// The per-frame products of slam::Frame::Frame (src/frame/frame.cpp:14-38).
+// ---------------------------------------------------------------------------
+struct FrameData {
+    std::vector<KeyPoint> keypoints, undistortedKeypoints;
+    Descriptors descriptors;
+    std::vector<float> scales, sigma, invSigma;
+};
+
+// distortion0: first distortion coefficient; the reference copies the keypoints
+// when it is zero (frame.cpp:42-45), which holds for the shipped calibration.
+// A non-zero value needs cv::undistortPoints, which this layer does not replace.
+inline FrameData makeFrame(Detector& detector, const Image8& image, float distortion0 = 0.0f) {
+    FrameData f;
+    detector.detect(image, f.keypoints, f.descriptors);
+    if (f.keypoints.empty()) return f;
+    if (distortion0 != 0.0f)
+        throw Error(SLAM_AMD_ERR_UNSUPPORTED, "keypoint undistortion is outside this layer (frame.cpp:46-65)");
+    f.undistortedKeypoints = f.keypoints;
+    const float scale = static_cast<float>(detector.getScaleFactor());
+    f.sigma.push_back(1.0f);
+    f.invSigma.push_back(1.0f);
+    f.scales.push_back(1.0f);
+    for (int i = 1; i < detector.getLevels(); i++) {
+        f.scales.push_back(f.scales[i - 1] * scale);
+        f.sigma.push_back(f.scales[i] * f.scales[i]);
+        f.invSigma.push_back(1.0f / f.sigma[i]);
+    }
+    return f;
+}
+
+// ---------------------------------------------------------------------------
+// What Matcher reads from a slam::KeyFrame.
+// ---------------------------------------------------------------------------
+struct KeyFrameView {
+    const uint8_t* descriptors = nullptr;       // frame->descriptors, N x 32
+    const KeyPoint* undistortedKeypoints = nullptr;  // frame->undistortedKeypoints, N records
+    int n = 0;
+    // keys of keyframe->mappoints in std::map order (ascending keypoint id) and the
+    // world position of each (MapPoint::getWorldPos)
+    const int* mappointIds = nullptr;
+    const Point3f* mappointPositions = nullptr;
+    int nMappoints = 0;
+    const float* pose = nullptr;                // KeyFrame::getPose(): 4 x 4, row-major, float
+    double fx = 0, fy = 0, cx = 0, cy = 0;      // frame->cameraMatrix
+    const double* distortions = nullptr;        // k1 k2 p1 p2 k3, or null for none
+};
+
+// ---------------------------------------------------------------------------
+// Matcher: replaces cv::BFMatcher::radiusMatch + Matcher::_filterMatches.
+// ---------------------------------------------------------------------------
+class Matcher {
+public:
+    explicit Matcher(int device = 0) { check(slam_amd_matcher_create(device, &m_)); }
+    Matcher(const Matcher&) = delete;
+    Matcher& operator=(const Matcher&) = delete;
+    ~Matcher() { slam_amd_matcher_destroy(m_); }
+
+    // reference: Matcher::frameMatch, src/frame/matcher.cpp:15-55
+    std::vector<DMatch> frameMatch(const KeyFrameView& keyframe1, const KeyFrameView& keyframe2,
+                                   const std::vector<int>& ids, float maximumDistance = 300,
+                                   float areaSize = -1, int maxLevel = 4) const {
+        return run(keyframe1, keyframe2, ids, nullptr, maximumDistance, areaSize, maxLevel);
+    }
+
+    // reference: Matcher::mappointsFrameMatch, src/frame/matcher.cpp:57-66
+    std::vector<DMatch> mappointsFrameMatch(const KeyFrameView& keyframe1, const KeyFrameView& keyframe2,
+                                            float maximumDistance = 300, float areaSize = -1,
+                                            int maxLevel = 4) const {
+        std::vector<int> ids(keyframe1.mappointIds, keyframe1.mappointIds + keyframe1.nMappoints);
+        // an empty id list means "all keypoints" in frameMatch (matcher.cpp:26,37-40)
+        return frameMatch(keyframe1, keyframe2, ids, maximumDistance, areaSize, maxLevel);
+    }
+
+    // reference: Matcher::inverseMappointsFrameMatch, src/frame/matcher.cpp:68-88
+    std::vector<DMatch> inverseMappointsFrameMatch(const KeyFrameView& keyframe1, const KeyFrameView& keyframe2,
+                                                   float maximumDistance = 300, float areaSize = -1,
+                                                   int maxLevel = 4) const {
+        if (keyframe1.nMappoints == 0)
+            return frameMatch(keyframe1, keyframe2, {}, maximumDistance, areaSize, maxLevel);
+        std::vector<int> all(static_cast<size_t>(keyframe1.n)), matchIds;
+        for (int i = 0; i < keyframe1.n; i++) all[static_cast<size_t>(i)] = i;
+        std::set_difference(all.begin(), all.end(), keyframe1.mappointIds,
+                            keyframe1.mappointIds + keyframe1.nMappoints, std::back_inserter(matchIds));
+        // like the reference, an empty difference falls through to "all keypoints"
+        return frameMatch(keyframe1, keyframe2, matchIds, maximumDistance, areaSize, maxLevel);
+    }
+
+    // reference: Matcher::projectionMatch, src/frame/matcher.cpp:90-129.  Queries are
+    // the map points of fromKeyFrame (ascending keypoint id); with areaSize != -1
+    // their positions are the map points projected with toKeyFrame's pose.
+    std::vector<DMatch> projectionMatch(const KeyFrameView& fromKeyFrame, const KeyFrameView& toKeyFrame,
+                                        float maximumDistance = 300, float areaSize = -1,
+                                        int maxLevel = 4) const {
+        const int nq = fromKeyFrame.nMappoints;
+        if (nq == 0) return {};
+        std::vector<int> ids(fromKeyFrame.mappointIds, fromKeyFrame.mappointIds + nq);
+        std::vector<Point2f> projected;
+        if (areaSize != -1) projected = projectMapPoints(fromKeyFrame, toKeyFrame);
+        return run(fromKeyFrame, toKeyFrame, ids, projected.empty() ? nullptr : &projected[0].x,
+                   maximumDistance, areaSize, maxLevel);
+    }
+
+    // reference: Matcher::_projectMapPoints, src/frame/matcher.cpp:163-184
+    std::vector<Point2f> projectMapPoints(const KeyFrameView& fromKeyFrame, const KeyFrameView& toKeyFrame) const {
+        std::vector<Point2f> points(static_cast<size_t>(fromKeyFrame.nMappoints));
+        if (points.empty()) return points;
+        if (!toKeyFrame.pose || !fromKeyFrame.mappointPositions)
+            throw Error(SLAM_AMD_ERR_ARG, "projection needs the target pose and the map point positions");
+        double Rt[12];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) Rt[r * 4 + c] = static_cast<double>(toKeyFrame.pose[r * 4 + c]);
+        const double K4[4] = {toKeyFrame.fx, toKeyFrame.fy, toKeyFrame.cx, toKeyFrame.cy};
+        check(slam_amd_project_points(m_, Rt, K4, toKeyFrame.distortions, &fromKeyFrame.mappointPositions[0].x,
+                                      fromKeyFrame.nMappoints, &points[0].x));
+        return points;
+    }
+
+    // reference: Mapper::_isDuplicate over every pair of Mapper::_keyframeDuplicates,
+    // src/tracking/mapper.cpp:292-346.  flag[i * n2 + j] != 0 where the descriptors are
+    // within descriptorDistance and the world points closer than pointDistance.
+    std::vector<uint8_t> duplicatePairs(const uint8_t* desc1, const Point3f* pos1, int n1,
+                                        const uint8_t* desc2, const Point3f* pos2, int n2,
+                                        int descriptorDistance = 100, double pointDistance = 1e-2) const {
+        std::vector<uint8_t> flag(static_cast<size_t>(n1) * static_cast<size_t>(n2));
+        if (flag.empty()) return flag;
+        check(slam_amd_duplicate_pairs(m_, desc1, &pos1[0].x, n1, desc2, &pos2[0].x, n2, descriptorDistance,
+                                       pointDistance, flag.data()));
+        return flag;
+    }
+
+    slam_amd_matcher* handle() const { return m_; }
+
+private:
+    std::vector<DMatch> run(const KeyFrameView& kf1, const KeyFrameView& kf2, const std::vector<int>& ids,
+                            const float* q_xy, float maximumDistance, float areaSize, int maxLevel) const {
+        const int nq = ids.empty() ? kf1.n : static_cast<int>(ids.size());
+        std::vector<DMatch> matches(static_cast<size_t>(std::max(nq, 0)));
+        int n = 0;
+        check(slam_amd_frame_match(m_, kf1.descriptors, reinterpret_cast<const slam_amd_keypoint*>(kf1.undistortedKeypoints),
+                                   kf1.n, kf2.descriptors,
+                                   reinterpret_cast<const slam_amd_keypoint*>(kf2.undistortedKeypoints), kf2.n,
+                                   ids.empty() ? nullptr : ids.data(), static_cast<int>(ids.size()), q_xy,
+                                   maximumDistance, areaSize, maxLevel,
+                                   reinterpret_cast<slam_amd_dmatch*>(matches.data()), &n));
+        matches.resize(static_cast<size_t>(n));
+        return matches;
+    }
+    slam_amd_matcher* m_ = nullptr;
+};
+
+}  // namespace slam_amd
+
+#endif
