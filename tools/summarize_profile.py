@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile_round.sh output directory into one text summary for profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src = sys.argv[1]
+out = []
+
+
+def kernel_short(n):
+    n = n.replace("sa::", "").replace("void ", "")
+    return n.split("(")[0][:60]
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+if stats:
+    out.append("== rocprofv3 --kernel-trace --stats (all calls of the run, warm-up and batch-1 latency loop included) ==")
+    out.append("%-62s %7s %12s %12s %12s" % ("kernel", "calls", "avg_us", "min_us", "max_us"))
+    for r in csv.DictReader(open(stats[0])):
+        out.append("%-62s %7s %12.2f %12.2f %12.2f" % (kernel_short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                      float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+trace = glob.glob(os.path.join(src, "trace", "*", "*kernel_trace.csv"))
+if trace:
+    # timed-region launches = the largest grid of each kernel (batch 32)
+    rows = list(csv.DictReader(open(trace[0])))
+    byk = collections.defaultdict(list)
+    for r in rows:
+        g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) if "Grid_Size_X" in r else int(r.get("Grid_Size", 0))
+        byk[kernel_short(r["Kernel_Name"])].append((g, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    out.append("")
+    out.append("== per kernel, launches with the largest grid only (the batch-32 steps of the timed region) ==")
+    out.append("%-62s %7s %12s" % ("kernel", "calls", "avg_us"))
+    for k, v in sorted(byk.items(), key=lambda kv: -sum(t for g, t in kv[1])):
+        gmax = max(g for g, t in v)
+        sel = [t for g, t in v if g == gmax]
+        out.append("%-62s %7d %12.2f" % (k, len(sel), sum(sel) / len(sel)))
+for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    files = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))
+    if not files:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(files[0])):
+        agg[kernel_short(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+    out.append("")
+    out.append("== rocprofv3 --pmc (%s): per-launch value, launches with the largest grid ==" % name)
+    for k, cs in agg.items():
+        if not k or k.startswith("at::") or k.startswith("__amd"):
+            continue
+        parts = []
+        for c, v in cs.items():
+            gmax = max(g for g, _ in v)
+            sel = [x for g, x in v if g == gmax]
+            parts.append("%s=%.0f" % (c, sum(sel) / len(sel)))
+        out.append("%-62s %s" % (k, "  ".join(parts)))
+for j in ("trace_bench.json",):
+    p = os.path.join(src, j)
+    if os.path.exists(p) and os.path.getsize(p):
+        out.append("")
+        out.append("== bench.py line of the traced run ==")
+        out.append(open(p).read().strip())
+print("\n".join(out))
