@@ -53,7 +53,15 @@ def main():
     ap.add_argument("--no-pairs", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=60)
+    ap.add_argument("--workload", default="frames", choices=["frames", "stream4k", "projection"],
+                    help="frames: BASELINE configs[1] (default, the driver's line); stream4k: configs[4]; "
+                         "projection: configs[2]")
+    ap.add_argument("--stream-frames", type=int, default=300)
     args = ap.parse_args()
+    if args.workload == "stream4k":
+        return run_stream4k(args)
+    if args.workload == "projection":
+        return run_projection(args)
 
     import torch
     import torch.distributed as dist
@@ -241,6 +249,114 @@ def run_pairs(args, torch, dist, capi, synth, m, dev, rank, world, barrier):
         out = pg.result()
         res["checksum"] = int(out.to(torch.int64).sum().item())
     return res
+
+
+def run_stream4k(args):
+    """BASELINE configs[4]: 3840x2160 stream, 10000 features, extract + match vs previous frame,
+    frames arriving in pinned host memory, H2D / compute / D2H overlapped on three streams."""
+    import torch
+    from slam_amd import capi, synth
+    from slam_amd.stream import FramePipeline
+    W, H, NF, CAP = 3840, 2160, 10000, 12288
+    n = args.stream_frames
+    seq = synth.frame_sequence(W, H, 4, seed=1)
+    pipe = FramePipeline(torch, W, H, capi.orb_params(nfeatures=NF), CAP, depth=4)
+    for i in range(pipe.depth):                 # a producer would write here; pre-filled once
+        pipe.h_img[i].numpy()[...] = seq[i % len(seq)]
+    for i in range(8):                          # warm-up
+        pipe.slot_image(i); pipe.submit(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(8, 8 + n):
+        pipe.slot_image(i)                      # waits until the slot's previous results are out
+        pipe.submit(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kp, desc, matches = pipe.result(8 + n - 1)
+    # the same work with the frames already resident in HBM and no result copies
+    pipe2 = FramePipeline(torch, W, H, capi.orb_params(nfeatures=NF), CAP, depth=4, copy_results=False)
+    d_frames = [torch.from_numpy(seq[i % len(seq)]).cuda() for i in range(4)]
+    st = torch.cuda.current_stream().cuda_stream
+
+    def resident_step(i):
+        s_, p_ = i % 4, (i - 1) % 4
+        pipe2.ex.extract_batch_async(d_frames[s_], 1, 0, W, pipe2.d_kp[s_], pipe2.d_desc[s_], pipe2.d_cnt[s_], CAP, st)
+        pipe2.m.frame_match_async(pipe2.d_desc[p_], pipe2.d_kp[p_], CAP, pipe2.d_cnt[p_], pipe2.d_desc[s_],
+                                  pipe2.d_kp[s_], CAP, pipe2.d_cnt[s_], pipe2.d_match[s_], pipe2.d_nmatch[s_],
+                                  max_dist=300.0, area=-1.0, max_level=-1, stream=st)
+    for i in range(8):
+        resident_step(i)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(8, 8 + n):
+        resident_step(i)
+    torch.cuda.synchronize()
+    dt2 = time.perf_counter() - t1
+    pipe.close(); pipe2.close()
+    print(json.dumps({
+        "metric": "frames/s ORB extract+match @3840x2160 10k feats, pipelined stream", "unit": "frames/s",
+        "value": round(n / dt2, 2), "value_including_h2d_and_d2h": round(n / dt, 2),
+        "n_gpus": 1, "steps": n, "ms_per_frame_resident": round(dt2 / n * 1e3, 4),
+        "ms_per_frame_pipelined": round(dt / n * 1e3, 4),
+        "h2d_bytes_per_frame": W * H, "d2h_bytes_per_frame": CAP * (28 + 32 + 16) + 8,
+        "keypoints_last_frame": len(kp), "matches_last_frame": len(matches),
+        "config": {"workload": "3840x2160 synthetic stream, 10000 ORB features, match vs previous frame, "
+                               "frames in pinned host memory, 3 streams, 4 slots"},
+        "data": "synthetic", "dtype": "u8"}), flush=True)
+
+
+def run_projection(args):
+    """BASELINE configs[2]: 1241x376 frames, 4000 features; 20000 map-point descriptors with
+    projected positions matched against the frame's keypoints, window 50 px, maxLevel 4."""
+    import torch
+    from slam_amd import capi, synth
+    W, H, NF, CAP, NQ = 1241, 376, 4000, 8192, 20000
+    dev = torch.device("cuda", 0)
+    ex = capi.Extractor(capi.orb_params(nfeatures=NF), W, H, max_batch=1, max_keypoints=CAP)
+    m = capi.Matcher()
+    m.reserve(NQ)
+    seq = synth.frame_sequence(W, H, 4, seed=2)
+    d_frames = [torch.from_numpy(f).cuda() for f in seq]
+    d_kp = torch.zeros(CAP * 28, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(CAP * 32, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    # local map: 20000 points whose descriptors are noisy copies of frame descriptors
+    kp0, desc0 = ex.extract(seq[0])
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, len(kp0), NQ)
+    q_desc = torch.from_numpy(synth.noisy_copy(desc0[src], 20, 1)).cuda()
+    q_kp_np = kp0[src].copy()
+    q_kp = torch.from_numpy(q_kp_np.view(np.uint8).copy()).cuda()
+    q_xy = torch.from_numpy(np.stack([q_kp_np["x"] + rng.normal(0, 8, NQ), q_kp_np["y"] + rng.normal(0, 8, NQ)],
+                                     1).astype(np.float32)).cuda()
+    ids = torch.arange(NQ, dtype=torch.int32, device=dev)
+    d_out = torch.zeros(NQ * 16, dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        ex.extract_batch_async(d_frames[i % 4], 1, 0, W, d_kp, d_desc, d_cnt, CAP, st)
+        m.frame_match_async(q_desc, q_kp, NQ, None, d_desc, d_kp, CAP, d_cnt, d_out, d_n, d_ids=ids, n_ids=NQ,
+                            d_q_xy=q_xy, max_dist=300.0, area=50.0, max_level=4, stream=st)
+    for i in range(args.warmup):
+        step(i)
+    capi.prof_enable(args.steps * 12 + 16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stages = capi.prof_collect()
+    n_t = int(d_cnt.item())
+    print(json.dumps({
+        "metric": "frames/s ORB extract + projection-windowed match @1241x376 4k feats vs 20k map points",
+        "unit": "frames/s", "value": round(args.steps / dt, 2), "n_gpus": 1, "steps": args.steps,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "keypoints": n_t, "matches": int(d_n.item()),
+        "match_gcmp_per_s": round(NQ * n_t / (stages["match"][0] / stages["match"][1] * 1e-3) / 1e9, 1),
+        "stage_us_per_launch": {k: round(v[0] / v[1] * 1e3, 2) for k, v in stages.items()},
+        "data": "synthetic", "dtype": "u8"}), flush=True)
+    ex.close(); m.close()
 
 
 def cpu_baseline(args, synth, seq):

@@ -182,6 +182,9 @@ __device__ __forceinline__ void list_append(bool flag, unsigned value, uint16_t*
 }
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef short ss2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ss2 as_ss2(unsigned v) { return __builtin_bit_cast(ss2, v); }
+__device__ __forceinline__ unsigned as_u32s(ss2 v) { return __builtin_bit_cast(unsigned, v); }
 
 __device__ __forceinline__ us2 as_us2(unsigned v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ unsigned as_u32(us2 v) { return __builtin_bit_cast(unsigned, v); }
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     uint16_t* s_list1 = reinterpret_cast<uint16_t*>(s_scratch);
     uint16_t* s_list2 = reinterpret_cast<uint16_t*>(s_scratch + kListBytes);
     unsigned* s_row = reinterpret_cast<unsigned*>(s_scratch);  // [38][32] packed u16 pairs
+    static_assert(kScPitch == kImgPitch, "score tile and image tile share one pitch");
     static_assert(kRowRows * kFastTileW * 2 <= 2 * kListBytes, "row-pass buffer must fit the scratch region");
 
     const int b = blockIdx.y;
@@ -226,77 +230,136 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     const int tid = threadIdx.x;
     s_hist[tid] = 0;
     if (tid < 2) s_n[tid] = 0;
-    for (int i = tid; i < kScRows * kScPitch / 4; i += 256) reinterpret_cast<unsigned*>(s_sc)[i] = 0;
+    // Thread (column group cg, row rr) of an 18 x 14 arrangement: one dword column
+    // of the staged tile, rows rr, rr + 14, rr + 28.  252 of the 256 threads take part.
+    const int rr = tid / 18, cg = tid - rr * 18;
+    const bool in_grid = tid < 252;
     // ---- stage image tile + halo, reflect-101 outside the image ----
-    {
-        constexpr int kDw = kImgPitch / 4;  // 18 dwords per row
-        for (int i = tid; i < kDw * kImgRows; i += 256) {
-            const int r = i / kDw, c = i - r * kDw;
-            const int gy = reflect101(y0 - kImgHalo + r, h);
-            const int gx = x0 - kImgHalo + 4 * c;
-            const uint8_t* row = img + (size_t)gy * pitch;
-            uint32_t v;
-            if (aligned && gx >= 0 && gx + 3 < w) {
-                v = *reinterpret_cast<const uint32_t*>(row + gx);
-            } else {
-                v = 0;
+    if (in_grid) {
+        const int gx = x0 - kImgHalo + 4 * cg;
+        const bool fast = aligned && gx >= 0 && gx + 3 < w;
+        int rx[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) v |= (uint32_t)row[reflect101(gx + j, w)] << (8 * j);
+        for (int j = 0; j < 4; j++) rx[j] = reflect101(gx + j, w);
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            const int r = rr + 14 * it;
+            if (r < kImgRows) {
+                const int gy = reflect101(y0 - kImgHalo + r, h);
+                const uint8_t* row = img + (size_t)gy * pitch;
+                uint32_t v;
+                if (fast) {
+                    v = *reinterpret_cast<const uint32_t*>(row + gx);
+                } else {
+                    v = (uint32_t)row[rx[0]] | ((uint32_t)row[rx[1]] << 8) | ((uint32_t)row[rx[2]] << 16) |
+                        ((uint32_t)row[rx[3]] << 24);
+                }
+                *reinterpret_cast<uint32_t*>(s_img + r * kImgPitch + 4 * cg) = v;
             }
-            *reinterpret_cast<uint32_t*>(s_img + r * kImgPitch + 4 * c) = v;
         }
     }
     __syncthreads();
     const int t = a.g.fast_threshold;
-    // ---- phase 1: compass test on the tile plus a 1-pixel halo ----
-    for (int i0 = 0; i0 < kScN; i0 += 256) {
-        const int i = i0 + tid;
-        bool pass = false;
-        if (i < kScN) {
-            const int r = i / kScW, c = i - r * kScW;
-            const int gx = x0 - 1 + c, gy = y0 - 1 + r;
-            if (gx >= 3 && gx < w - 3 && gy >= 3 && gy < h - 3) {
-                const uint8_t* p = s_img + (r + 3) * kImgPitch + (c + 3);
-                const int v = p[0];
-                const int d0 = v - p[3 * kImgPitch], d4 = v - p[3], d8 = v - p[-3 * kImgPitch], d12 = v - p[-3];
-                const int nd = (d0 > t) + (d4 > t) + (d8 > t) + (d12 > t);
-                const int nb = (d0 < -t) + (d4 < -t) + (d8 < -t) + (d12 < -t);
-                pass = nd >= 2 || nb >= 2;
+    // ---- phase 1: compass test, 4 pixels per item, packed 16-bit arithmetic ----
+    // Item (row r of the scored region, column group cg) covers staged columns
+    // 4cg .. 4cg+3 of staged row r + 3.  With d = centre - compass pixel for the four
+    // compass points, a 9-arc needs two of them beyond the threshold on one side:
+    // second largest d > t (darker) or second smallest d < -t (brighter).
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+        const int r = rr + 14 * it;
+        unsigned pass4 = 0;
+        if (in_grid && r < kScRows) {
+            const uint32_t* rowc = reinterpret_cast<const uint32_t*>(s_img + (r + 3) * kImgPitch);
+            const uint32_t C = rowc[cg];
+            const uint32_t Wm = cg > 0 ? rowc[cg - 1] : 0u;
+            const uint32_t Wp = cg < 17 ? rowc[cg + 1] : 0u;
+            const uint32_t U = reinterpret_cast<const uint32_t*>(s_img + r * kImgPitch)[cg];
+            const uint32_t D = reinterpret_cast<const uint32_t*>(s_img + (r + 6) * kImgPitch)[cg];
+            const uint32_t L = __builtin_amdgcn_alignbyte(C, Wm, 1);   // columns -3
+            const uint32_t R = __builtin_amdgcn_alignbyte(Wp, C, 3);   // columns +3
+            reinterpret_cast<uint32_t*>(s_sc)[r * (kScPitch / 4) + cg] = 0;  // clears the score tile
+            const ss2 T2 = {(short)t, (short)t};
+            unsigned f[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                const unsigned sel = hf ? 0x0c030c02u : 0x0c010c00u;
+                const ss2 c = as_ss2(__builtin_amdgcn_perm(0u, C, sel));
+                const ss2 d0 = c - as_ss2(__builtin_amdgcn_perm(0u, D, sel));
+                const ss2 d4 = c - as_ss2(__builtin_amdgcn_perm(0u, R, sel));
+                const ss2 d8 = c - as_ss2(__builtin_amdgcn_perm(0u, U, sel));
+                const ss2 d12 = c - as_ss2(__builtin_amdgcn_perm(0u, L, sel));
+                const ss2 hi1 = __builtin_elementwise_max(d0, d8), lo1 = __builtin_elementwise_min(d0, d8);
+                const ss2 hi2 = __builtin_elementwise_max(d4, d12), lo2 = __builtin_elementwise_min(d4, d12);
+                const ss2 m1 = __builtin_elementwise_min(hi1, hi2), m2 = __builtin_elementwise_max(lo1, lo2);
+                const ss2 second_hi = __builtin_elementwise_max(m1, m2), second_lo = __builtin_elementwise_min(m1, m2);
+                // sign bit of each 16-bit half set <=> that pixel passes
+                f[hf] = as_u32s(T2 - second_hi) | as_u32s(second_lo + T2);
             }
+            pass4 = ((f[0] >> 15) & 1u) | ((f[0] >> 30) & 2u) | ((f[1] >> 13) & 4u) | ((f[1] >> 28) & 8u);
+            // positions outside the scored region or within 3 pixels of the image edge
+            const int col0 = 4 * cg;                    // staged column of pixel 0
+            const int gx0 = x0 - kImgHalo + col0;
+            const int gy = y0 - 1 + r;
+            int jmin = max(3 - col0, 3 - gx0), jmax = min(69 - col0, (w - 3) - gx0);
+            jmin = max(jmin, 0); jmax = min(jmax, 4);
+            unsigned vmask = (jmax > jmin && gy >= 3 && gy < h - 3) ? (((1u << jmax) - 1u) & ~((1u << jmin) - 1u)) : 0u;
+            pass4 &= vmask;
         }
-        list_append(pass, (unsigned)i, s_list1, &s_n[0]);
+        // append the staged offsets of the passing pixels to list 1
+        const int lane = tid & 63;
+        const unsigned long long b0 = __ballot(pass4 & 1u), b1 = __ballot(pass4 & 2u),
+                                 b2 = __ballot(pass4 & 4u), b3 = __ballot(pass4 & 8u);
+        const int n0 = __builtin_popcountll(b0), n01 = n0 + __builtin_popcountll(b1),
+                  n012 = n01 + __builtin_popcountll(b2), total = n012 + __builtin_popcountll(b3);
+        if (total) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s_n[0], (unsigned)total);
+            base = __shfl(base, 0, 64);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned code = (unsigned)((r + 3) * kImgPitch + 4 * cg);
+            if (pass4 & 1u) s_list1[base + __builtin_popcountll(b0 & lt)] = (uint16_t)code;
+            if (pass4 & 2u) s_list1[base + n0 + __builtin_popcountll(b1 & lt)] = (uint16_t)(code + 1);
+            if (pass4 & 4u) s_list1[base + n01 + __builtin_popcountll(b2 & lt)] = (uint16_t)(code + 2);
+            if (pass4 & 8u) s_list1[base + n012 + __builtin_popcountll(b3 & lt)] = (uint16_t)(code + 3);
+        }
     }
     __syncthreads();
     // ---- phase 2: full ring, 9 contiguous darker or brighter ----
+    // One subtract and one funnel shift per flag: the sign of (ring - (v - t)) says
+    // "darker", the sign of ((v + t) - ring) "brighter"; alignbit shifts it into the mask.
     const int n1 = (int)s_n[0];
     for (int k0 = 0; k0 < n1; k0 += 256) {
         const int k = k0 + tid;
         bool corner = false;
-        unsigned i = 0;
+        unsigned code = 0;
         if (k < n1) {
-            i = s_list1[k];
-            const int r = i / kScW, c = i - r * kScW;
-            int d[16];
-            ring_diffs(s_img + (r + 3) * kImgPitch + (c + 3), d);
+            code = s_list1[k];
+            const uint8_t* p = s_img + code;
+            const int v = p[0];
+            const unsigned lo = (unsigned)(v - t), hi = (unsigned)(v + t);
             unsigned dark = 0, bright = 0;
+            constexpr int P = kImgPitch;
+            constexpr int off[16] = {3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1,
+                                     -3 * P, -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3, 2 * P - 2, 3 * P - 1};
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                dark |= (unsigned)(d[j] > t) << j;
-                bright |= (unsigned)(d[j] < -t) << j;
+                const unsigned ring = p[off[j]];
+                dark = __builtin_amdgcn_alignbit(dark, ring - lo, 31);
+                bright = __builtin_amdgcn_alignbit(bright, hi - ring, 31);
             }
             corner = has_run9(dark) || has_run9(bright);
         }
-        list_append(corner, i, s_list2, &s_n[1]);
+        list_append(corner, code, s_list2, &s_n[1]);
     }
     __syncthreads();
     // ---- phase 3: score of the corners ----
     const int n2 = (int)s_n[1];
     for (int k = tid; k < n2; k += 256) {
-        const unsigned i = s_list2[k];
-        const int r = i / kScW, c = i - r * kScW;
+        const unsigned code = s_list2[k];
         int d[16];
-        ring_diffs(s_img + (r + 3) * kImgPitch + (c + 3), d);
-        s_sc[r * kScPitch + c + 3] = (uint8_t)fast_corner_score(d, t);
+        ring_diffs(s_img + code, d);
+        s_sc[code - 3 * kImgPitch] = (uint8_t)fast_corner_score(d, t);   // same pitch, 3 rows up
     }
     __syncthreads();
     // ---- phase 4a: NMS + border filter, 4 pixels per thread ----

@@ -170,8 +170,9 @@ __global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
 // Keys -> cv::DMatch records in ascending query order, one workgroup per problem.
 
 __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) {
+    // Every thread owns a contiguous run of queries: count its matches, one
+    // workgroup-wide exclusive scan of the 1024 counts, then write the run.
     __shared__ int s_wave[16];
-    __shared__ int s_base;
     const int prob = blockIdx.x;
     int n1 = a.n1;
     if (a.d_n1) n1 = min(n1, a.d_n1[prob]);
@@ -179,37 +180,38 @@ __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) 
     const unsigned* best = a.best + (size_t)prob * a.cap1;
     slam_amd_dmatch* out = a.out + (size_t)prob * a.cap1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_base = 0;
-    __syncthreads();
-    for (int q0 = 0; q0 < nq; q0 += 1024) {
-        const int qi = q0 + threadIdx.x;
-        unsigned key = kNoMatch;
-        if (qi < nq) key = best[qi];
-        const unsigned d = key >> kIdxBits;
-        const bool has = key != kNoMatch && (int)d <= a.dmax;
-        const unsigned long long m = __ballot(has);
-        if (lane == 0) s_wave[wave] = __builtin_popcountll(m);
-        __syncthreads();
-        int before = s_base;
-        for (int w = 0; w < wave; w++) before += s_wave[w];
-        if (has) {
-            const int pos = before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-            slam_amd_dmatch r;
-            r.queryIdx = a.ids ? a.ids[qi] : qi;
-            r.trainIdx = (int)(key & ((1u << kIdxBits) - 1));
-            r.imgIdx = 0;
-            r.distance = (float)d;
-            out[pos] = r;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
-            for (int w = 0; w < 16; w++) tot += s_wave[w];
-            s_base += tot;
-        }
-        __syncthreads();
+    const int per = (nq + 1023) / 1024;
+    const int q0 = min((int)threadIdx.x * per, nq), q1 = min(q0 + per, nq);
+    auto valid = [&](unsigned key) { return key != kNoMatch && (int)(key >> kIdxBits) <= a.dmax; };
+    int cnt = 0;
+    for (int q = q0; q < q1; q++) cnt += valid(best[q]);
+    // exclusive scan over the workgroup
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += n;
     }
-    if (threadIdx.x == 0) a.n_out[prob] = s_base;
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 16; w++) {
+        const int v = s_wave[w];
+        if (w < wave) before += v;
+        total += v;
+    }
+    int pos = before + inc - cnt;
+    for (int q = q0; q < q1; q++) {
+        const unsigned key = best[q];
+        if (!valid(key)) continue;
+        slam_amd_dmatch r;
+        r.queryIdx = a.ids ? a.ids[q] : q;
+        r.trainIdx = (int)(key & ((1u << kIdxBits) - 1));
+        r.imgIdx = 0;
+        r.distance = (float)(key >> kIdxBits);
+        out[pos++] = r;
+    }
+    if (threadIdx.x == 0) a.n_out[prob] = total;
 }
 
 // Pinhole projection with radial/tangential distortion, double arithmetic.

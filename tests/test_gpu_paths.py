@@ -329,3 +329,27 @@ def test_duplicate_pairs_vs_oracle(oracle, capi):
     m.close()
     ref = oracle.duplicate_pairs(d1, p1, d2, p2, 100, 1e-2)
     assert np.array_equal(got, ref) and ref.sum() > 10
+
+
+# ------------------------------------------------------------------ pipeline ----
+def test_frame_pipeline_matches_sequential_oracle(oracle, capi):
+    """Three-stream pipeline (H2D / extract + match / D2H) over a short sequence."""
+    torch = _torch()
+    from slam_amd.stream import FramePipeline
+    W, H, NF = 320, 240, 400
+    frames = synth.frame_sequence(W, H, 7, seed=5)
+    pipe = FramePipeline(torch, W, H, capi.orb_params(nfeatures=NF), 2048, depth=3,
+                         max_dist=300.0, area=50.0, max_level=4)
+    got = pipe.run(frames, keep_results=True)
+    pipe.close()
+    po = oracle.params(nfeatures=NF)
+    prev = None
+    assert len(got) == len(frames)
+    for i, f in enumerate(frames):
+        kp_o, d_o = oracle.detect_and_compute(po, f)
+        kp, d, mt = got[i]
+        assert kp.tobytes() == kp_o.tobytes() and np.array_equal(d, d_o), i
+        if prev is not None:
+            ref = oracle.match_gated(prev[1], prev[0], d_o, kp_o, 300.0, 50.0, 4)
+            assert mt.tobytes() == ref.tobytes(), i
+        prev = (kp_o, d_o)
