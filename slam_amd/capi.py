@@ -28,7 +28,7 @@ EXPORTS = [
     "slam_amd_default_orb_params",
     "slam_amd_extractor_create", "slam_amd_extractor_destroy", "slam_amd_extractor_levels",
     "slam_amd_extract", "slam_amd_extract_batch_async", "slam_amd_extractor_debug_level",
-    "slam_amd_extractor_debug_blurred_level",
+    "slam_amd_extractor_debug_blurred_level", "slam_amd_extractor_debug_set_row_list_capacity",
     "slam_amd_matcher_create", "slam_amd_matcher_destroy", "slam_amd_matcher_reserve",
     "slam_amd_frame_match", "slam_amd_frame_match_async", "slam_amd_frame_match_batch_async",
     "slam_amd_match_pairs_async",
@@ -98,6 +98,7 @@ def lib():
         l.slam_amd_extractor_levels.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         l.slam_amd_extractor_debug_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         l.slam_amd_extractor_debug_blurred_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        l.slam_amd_extractor_debug_set_row_list_capacity.argtypes = [C.c_void_p, C.c_int]
         l.slam_amd_matcher_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         l.slam_amd_matcher_destroy.argtypes = [C.c_void_p]
         l.slam_amd_project_points.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
@@ -219,6 +220,9 @@ class Extractor:
         check(lib().slam_amd_extract_batch_async(self._h, _ptr(d_images), batch, frame_pitch, row_stride,
                                                   _ptr(d_kp), _ptr(d_desc), _ptr(d_count), capacity,
                                                   C.c_void_p(stream)))
+
+    def debug_set_row_list_capacity(self, entries):
+        check(lib().slam_amd_extractor_debug_set_row_list_capacity(self._h, entries))
 
     def debug_level(self, frame, level, blurred=False):
         ws, hs, _, _ = self.levels()

@@ -96,7 +96,7 @@ struct slam_amd_extractor {
     const int* yoff[kMaxLevels] = {};
     const uint16_t* yc1[kMaxLevels] = {};
     int lds_pitch[kMaxLevels] = {}, lds_rows[kMaxLevels] = {};
-    DevBuf pyr, smap, blur, hist, rowcnt, sel, kpxy;
+    DevBuf pyr, smap, blur, hist, rowlist, sel, kpxy;  // hist also holds the row fill counters
     // host-call staging
     DevBuf h_img, h_kp, h_desc, h_count;
     int h_img_pitch = 0;
@@ -181,6 +181,7 @@ static int build_geometry(slam_amd_extractor* ex) {
     g.frame_bytes = (off + 255u) & ~255u;
     g.total_rows = rows;
     g.total_tiles = tiles;
+    g.rowcap = kRowListCap;
     return SLAM_AMD_OK;
 }
 
@@ -260,8 +261,9 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
     if ((rc = ex->pyr.reserve(B * g.frame_bytes))) return fail(rc);
     if ((rc = ex->smap.reserve(B * g.frame_bytes))) return fail(rc);
     if ((rc = ex->blur.reserve(B * g.frame_bytes))) return fail(rc);
-    if ((rc = ex->hist.reserve(B * g.nlevels * 256 * sizeof(unsigned)))) return fail(rc);
-    if ((rc = ex->rowcnt.reserve(B * g.total_rows * sizeof(unsigned)))) return fail(rc);
+    // histogram and row fill counters share one allocation: one memset clears both
+    if ((rc = ex->hist.reserve(B * ((size_t)g.nlevels * 256 + g.total_rows) * sizeof(unsigned)))) return fail(rc);
+    if ((rc = ex->rowlist.reserve(B * (size_t)g.total_rows * kRowListCap * sizeof(uint32_t)))) return fail(rc);
     if ((rc = ex->sel.reserve(B * sizeof(FrameSelect)))) return fail(rc);
     if ((rc = ex->kpxy.reserve(B * (size_t)max_keypoints * sizeof(uint32_t)))) return fail(rc);
     hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
@@ -274,7 +276,7 @@ extern "C" int slam_amd_extractor_destroy(slam_amd_extractor* ex) {
     if (!ex) return SLAM_AMD_OK;
     (void)hipSetDevice(ex->device);
     if (ex->stream) { (void)hipStreamSynchronize(ex->stream); (void)hipStreamDestroy(ex->stream); }
-    for (DevBuf* b : {&ex->tables, &ex->pyr, &ex->smap, &ex->blur, &ex->hist, &ex->rowcnt, &ex->sel, &ex->kpxy,
+    for (DevBuf* b : {&ex->tables, &ex->pyr, &ex->smap, &ex->blur, &ex->hist, &ex->rowlist, &ex->sel, &ex->kpxy,
                       &ex->h_img, &ex->h_kp, &ex->h_desc, &ex->h_count})
         b->release();
     delete ex;
@@ -316,7 +318,7 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
 
     {
         ProfScope ps(kStageMemset, st);
-        SA_HIP(hipMemsetAsync(ex->hist.p, 0, (size_t)batch * g.nlevels * 256 * sizeof(unsigned), st));
+        SA_HIP(hipMemsetAsync(ex->hist.p, 0, (size_t)batch * ((size_t)g.nlevels * 256 + g.total_rows) * sizeof(unsigned), st));
     }
     int rc;
     prof_mark(kStageResize, true, st);
@@ -338,16 +340,15 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     prof_mark(kStageResize, false, st);
     FastArgs fa;
     fa.img0 = d_images; fa.img0_frame_pitch = frame_pitch; fa.img0_pitch = row_stride; fa.img0_aligned = aligned;
-    fa.pyr = ex->pyr.as<uint8_t>(); fa.smap = ex->smap.as<uint8_t>(); fa.blur = ex->blur.as<uint8_t>(); fa.hist = ex->hist.as<unsigned>(); fa.g = g;
+    fa.pyr = ex->pyr.as<uint8_t>(); fa.smap = ex->smap.as<uint8_t>(); fa.blur = ex->blur.as<uint8_t>(); fa.hist = ex->hist.as<unsigned>();
+    unsigned* rowfill = ex->hist.as<unsigned>() + (size_t)batch * g.nlevels * 256;
+    fa.rowfill = rowfill; fa.rowlist = ex->rowlist.as<uint32_t>(); fa.g = g;
     { ProfScope ps(kStageFast, st); if ((rc = launch_fast(fa, batch, st))) return rc; }
-    SelectArgs sa_;
-    sa_.hist = ex->hist.as<unsigned>(); sa_.sel = ex->sel.as<FrameSelect>(); sa_.d_count = d_count; sa_.g = g;
-    { ProfScope ps(kStageSelect, st); if ((rc = launch_select(sa_, batch, st))) return rc; }
-    CompactArgs ca;
-    ca.smap = ex->smap.as<uint8_t>(); ca.sel = ex->sel.as<FrameSelect>(); ca.rowcnt = ex->rowcnt.as<unsigned>();
-    ca.kp = d_kp; ca.kpxy = ex->kpxy.as<uint32_t>(); ca.capacity = capacity; ca.g = g;
-    { ProfScope ps(kStageCountRows, st); if ((rc = launch_count_rows(ca, batch, st))) return rc; }
-    { ProfScope ps(kStageCompactRows, st); if ((rc = launch_compact_rows(ca, batch, st))) return rc; }
+    SelectCompactArgs sc;
+    sc.hist = ex->hist.as<unsigned>(); sc.rowfill = rowfill; sc.rowlist = ex->rowlist.as<uint32_t>();
+    sc.smap = ex->smap.as<uint8_t>(); sc.sel = ex->sel.as<FrameSelect>(); sc.d_count = d_count;
+    sc.kp = d_kp; sc.kpxy = ex->kpxy.as<uint32_t>(); sc.capacity = capacity; sc.g = g;
+    { ProfScope ps(kStageSelect, st); if ((rc = launch_select_compact(sc, batch, st))) return rc; }
     DescribeArgs da;
     da.img0 = d_images; da.img0_frame_pitch = frame_pitch; da.img0_pitch = row_stride;
     da.img0_aligned = aligned; da.pyr = ex->pyr.as<uint8_t>(); da.blur = ex->blur.as<uint8_t>(); da.sel = ex->sel.as<FrameSelect>(); da.kp = d_kp;
@@ -412,6 +413,13 @@ static int debug_level(slam_amd_extractor* ex, int frame, int level, bool blurre
         SA_HIP(hipMemcpy2D(host_out, host_stride, base + (size_t)frame * ex->g.frame_bytes + L.off, L.pitch,
                            L.w, L.h, hipMemcpyDeviceToHost));
     }
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_extractor_debug_set_row_list_capacity(slam_amd_extractor* ex, int entries) {
+    if (!ex) SA_FAIL(SLAM_AMD_ERR_ARG, "extractor is null");
+    if (entries < 0 || entries > kRowListCap) SA_FAIL(SLAM_AMD_ERR_ARG, "entries out of range");
+    ex->g.rowcap = entries;
     return SLAM_AMD_OK;
 }
 
@@ -710,8 +718,8 @@ extern "C" int slam_amd_prof_collect(double* total_ms, int* calls, int n_stages)
 }
 
 extern "C" const char* slam_amd_prof_stage_name(int stage) {
-    static const char* names[kStageCount] = {"resize_level (all levels)", "fast_nms", "select_levels",
-        "count_rows", "compact_rows", "describe", "match", "finalize_matches", "match_pairs", "memset"};
+    static const char* names[kStageCount] = {"resize_level (all levels)", "fast_nms", "select_compact",
+        "(unused)", "(unused)", "describe", "match", "finalize_matches", "match_pairs", "memset"};
     return (stage >= 0 && stage < kStageCount) ? names[stage] : "";
 }
 

@@ -48,6 +48,7 @@ struct PyrGeom {
     int total_rows;     // sum of level heights
     int total_tiles;    // FAST tiles per frame
     unsigned frame_bytes;  // bytes of one frame's pyramid (and survivor map)
+    int rowcap;         // entries of a row's survivor list in use (<= kRowListCap)
     LevelGeom lv[kMaxLevels];
 };
 
@@ -62,7 +63,7 @@ struct FrameSelect {
 
 // Optional per-stage timing with HIP events on the stream the kernels run on.
 enum Stage {
-    kStageResize = 0, kStageFast, kStageSelect, kStageCountRows, kStageCompactRows, kStageDescribe,
+    kStageResize = 0, kStageFast, kStageSelect, kStageCountRows, kStageCompactRows, kStageDescribe,  // Select = select_compact; the two row stages are unused
     kStageMatch, kStageFinalize, kStageMatchPairs, kStageMemset, kStageCount
 };
 void prof_mark(int stage, bool begin, hipStream_t st);
@@ -71,6 +72,9 @@ struct ProfScope {
     ProfScope(int s, hipStream_t t) : stage(s), st(t) { prof_mark(stage, true, st); }
     ~ProfScope() { prof_mark(stage, false, st); }
 };
+
+// Survivor list of one image row: up to kRowListCap entries x | score << 16.
+constexpr int kRowListCap = 64;
 
 constexpr int kFastTileW = 64;
 constexpr int kFastTileH = 32;

@@ -2,10 +2,11 @@
 //
 // Per batch of frames, in stream order:
 //   resize_level  x (nlevels-1)  chained bit-exact bilinear pyramid
-//   fast_nms                      FAST-9/16 score + 3x3 NMS + border filter +
-//                                 per-level score histogram, all levels, one launch
-//   select_levels                 per-level cut score from the histogram (retain-best)
-//   count_rows / compact_rows     deterministic raster-order compaction -> keypoints
+//   fast_nms                      FAST-9/16 score + 3x3 NMS + border filter + per-level score
+//                                 histogram + per-row survivor lists + 7x7 blur, all levels, one launch
+//   select_compact                per-level cut score from the histogram (retain-best), then
+//                                 the kept survivors of every row's sparse list -> keypoints
+//                                 in canonical (octave, y, x) order
 //   describe                      intensity-centroid angle + 7x7 blur + rBRIEF,
 //                                 one wavefront per keypoint, patch held in LDS
 #include "common.h"
@@ -145,26 +146,24 @@ __device__ __forceinline__ void ring_diffs(const uint8_t* c, int (&d)[16]) {
     d[12] = v - c[-3];         d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
 }
 
-// Corner score: max(t, best arc of 9 by min |difference|) - 1, via sliding min/max.
+// Corner score: max(t, best arc of 9 by min |difference|) - 1.  Windows of 3 by
+// three-input min / max, windows of 9 from three windows of 3.
 __device__ __forceinline__ int fast_corner_score(const int (&d)[16], int t) {
-    int lo2[16], hi2[16], lo4[16], hi4[16];
+    int lo3[16], hi3[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        lo2[k] = min(d[k], d[(k + 1) & 15]);
-        hi2[k] = max(d[k], d[(k + 1) & 15]);
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
-        hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+        lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
     }
     int a0 = t, b0 = 255;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        a0 = max(a0, lo9);
-        b0 = min(b0, hi9);
+    for (int k = 0; k < 16; k += 2) {
+        const int lo9a = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
+        const int lo9b = min(min(lo3[k + 1], lo3[(k + 4) & 15]), lo3[(k + 7) & 15]);
+        const int hi9a = max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]);
+        const int hi9b = max(max(hi3[k + 1], hi3[(k + 4) & 15]), hi3[(k + 7) & 15]);
+        a0 = max(max(a0, lo9a), lo9b);
+        b0 = min(min(b0, hi9a), hi9b);
     }
     b0 = min(b0, -a0);
     return -b0 - 1;
@@ -387,6 +386,10 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
                         s > q[-kScPitch + 1] && s > q[kScPitch - 1] && s > q[kScPitch] && s > q[kScPitch + 1]) {
                         packed |= (uint32_t)s << (8 * j);
                         atomicAdd(&s_hist[s], 1u);
+                        const size_t row = (size_t)b * a.g.total_rows + L.row_base + gy;
+                        const unsigned slot = atomicAdd(&a.rowfill[row], 1u);
+                        if (slot < (unsigned)a.g.rowcap)
+                            a.rowlist[row * kRowListCap + slot] = (uint32_t)gx | ((uint32_t)s << 16);
                     }
                 }
             }
@@ -445,71 +448,17 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// Selection: KeyPointsFilter::retainBest per level, from the score histogram.
-// One workgroup per frame; wave k handles levels k, k+4, ...
+// Selection + compaction, one workgroup of 16 waves per (frame, level).
+//   1. KeyPointsFilter::retainBest from the score histograms: wave w takes level
+//      w (levels up to the workgroup's own), suffix sums over the 256 bins by
+//      shuffles -> cut score and kept count.  The level's first output index is
+//      the sum of the kept counts of the lower levels.
+//   2. One image row per thread: the survivors with score >= cut of the row's
+//      sparse list go to registers, the workgroup scans the counts, and every
+//      thread writes its keypoints in ascending x.  Rows in order and levels in
+//      order give the canonical (octave, y, x) order.
+// A row whose list overflowed is read from the dense survivor map instead.
 // ---------------------------------------------------------------------------
-
-__global__ __launch_bounds__(256) void select_levels_kernel(SelectArgs a) {
-    __shared__ int s_cut[kMaxLevels], s_cnt[kMaxLevels];
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int l = wave; l < a.g.nlevels; l += 4) {
-        const unsigned* h = a.hist + ((size_t)b * a.g.nlevels + l) * 256;
-        // lane owns bins 4*lane .. 4*lane+3; suffix sums over bins
-        unsigned v0 = h[4 * lane], v1 = h[4 * lane + 1], v2 = h[4 * lane + 2], v3 = h[4 * lane + 3];
-        unsigned own = v0 + v1 + v2 + v3;
-        // inclusive suffix scan over lanes (sum of lanes >= lane)
-        unsigned suf = own;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            unsigned n = __shfl_down(suf, o, 64);
-            if (lane + o < 64) suf += n;
-        }
-        const unsigned above = suf - own;  // bins of higher lanes
-        const unsigned s3 = above + v3, s2 = s3 + v2, s1 = s2 + v1, s0 = s1 + v0;
-        const unsigned total = __shfl(suf, 0, 64);
-        const unsigned quota = (unsigned)a.g.lv[l].quota;
-        int cut = 1, cnt = (int)total;
-        if (total > quota) {
-            if (quota == 0) {
-                cut = 256; cnt = 0;
-            } else {
-                // largest bin c with suffix(c) >= quota
-                int best = -1; unsigned bc = 0;
-                if (s3 >= quota) { best = 4 * lane + 3; bc = s3; }
-                else if (s2 >= quota) { best = 4 * lane + 2; bc = s2; }
-                else if (s1 >= quota) { best = 4 * lane + 1; bc = s1; }
-                else if (s0 >= quota) { best = 4 * lane; bc = s0; }
-                unsigned long long m = __ballot(best >= 0);
-                int top = 63 - __builtin_clzll(m);  // m != 0 because total > quota >= 1
-                cut = __shfl(best, top, 64);
-                cnt = (int)__shfl(bc, top, 64);
-            }
-        }
-        if (lane == 0) { s_cut[l] = cut; s_cnt[l] = cnt; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        FrameSelect fs;
-        int acc = 0;
-        for (int l = 0; l < kMaxLevels; l++) {
-            bool on = l < a.g.nlevels;
-            fs.cut[l] = on ? s_cut[l] : 256;
-            fs.count[l] = on ? s_cnt[l] : 0;
-            fs.offset[l] = acc;
-            acc += fs.count[l];
-        }
-        fs.total = acc;
-        fs.pad[0] = fs.pad[1] = fs.pad[2] = 0;
-        a.sel[b] = fs;
-        if (a.d_count) a.d_count[b] = acc;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Raster-order compaction of the survivor map, one wavefront per image row.
-// ---------------------------------------------------------------------------
-
 __device__ __forceinline__ int level_of_row(const PyrGeom& g, int row) {
     int l = 0;
 #pragma unroll 1
@@ -518,109 +467,170 @@ __device__ __forceinline__ int level_of_row(const PyrGeom& g, int row) {
     return l;
 }
 
-__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+__global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs a) {
+    __shared__ int s_cut[kMaxLevels], s_cnt[kMaxLevels];
+    __shared__ int s_wave[16];
+    const int b = blockIdx.x / a.g.nlevels;
+    const int my_level = blockIdx.x - b * a.g.nlevels;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave <= my_level) {
+        const int l = wave;
+        const unsigned* h = a.hist + ((size_t)b * a.g.nlevels + l) * 256;
+        // lane owns bins 4*lane .. 4*lane+3; suffix sums over bins
+        const unsigned v0 = h[4 * lane], v1 = h[4 * lane + 1], v2 = h[4 * lane + 2], v3 = h[4 * lane + 3];
+        const unsigned own = v0 + v1 + v2 + v3;
+        unsigned suf = own;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-constexpr int kRowsPerWave = 1;
-
-// Number of survivors with score >= cut in every row, kRowsPerWave rows per wave.
-__global__ __launch_bounds__(256) void count_rows_kernel(CompactArgs a) {
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kRowsPerWave;
-    if (row0 >= a.g.total_rows) return;
-    const int edge = a.g.edge;
-    unsigned cnt[kRowsPerWave];
-#pragma unroll
-    for (int k = 0; k < kRowsPerWave; k++) {
-        cnt[k] = 0;
-        const int row = row0 + k;
-        if (row >= a.g.total_rows) continue;
-        const int l = level_of_row(a.g, row);
-        const LevelGeom& L = a.g.lv[l];
-        const int y = row - L.row_base;
-        const unsigned cut = (unsigned)a.sel[b].cut[l];
-        if (cut < 256 && y >= edge && y < L.h - edge) {
-            const uint8_t* r = a.smap + (size_t)b * a.g.frame_bytes + L.off + (size_t)y * L.pitch;
-            for (int x = 4 * lane; x < L.pitch; x += 256) {
-                const uint32_t v = *reinterpret_cast<const uint32_t*>(r + x);
-                if (v == 0) continue;
-#pragma unroll
-                for (int j = 0; j < 4; j++) cnt[k] += ((v >> (8 * j)) & 255u) >= cut;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned n = __shfl_down(suf, o, 64);
+            if (lane + o < 64) suf += n;
+        }
+        const unsigned above = suf - own;
+        const unsigned s3 = above + v3, s2 = s3 + v2, s1 = s2 + v1, s0 = s1 + v0;
+        const unsigned total = __shfl(suf, 0, 64);
+        const unsigned quota = (unsigned)a.g.lv[l].quota;
+        int cut = 1, cnt = (int)total;
+        if (total > quota) {
+            if (quota == 0) {
+                cut = 256; cnt = 0;
+            } else {
+                // largest bin c with suffix(c) >= quota; ties at the cut are all kept
+                int best = -1; unsigned bc = 0;
+                if (s3 >= quota) { best = 4 * lane + 3; bc = s3; }
+                else if (s2 >= quota) { best = 4 * lane + 2; bc = s2; }
+                else if (s1 >= quota) { best = 4 * lane + 1; bc = s1; }
+                else if (s0 >= quota) { best = 4 * lane; bc = s0; }
+                const unsigned long long m = __ballot(best >= 0);
+                const int top = 63 - __builtin_clzll(m);  // m != 0 because total > quota >= 1
+                cut = __shfl(best, top, 64);
+                cnt = (int)__shfl(bc, top, 64);
             }
         }
+        if (lane == 0) { s_cut[l] = cut; s_cnt[l] = cnt; }
     }
-#pragma unroll
-    for (int k = 0; k < kRowsPerWave; k++) {
-        const unsigned c = wave_sum(cnt[k]);
-        if (lane == 0 && row0 + k < a.g.total_rows) a.rowcnt[(size_t)b * a.g.total_rows + row0 + k] = c;
-    }
-}
+    __syncthreads();
 
-// Writes the kept survivors of every row as keypoints, in raster order.
-__global__ __launch_bounds__(256) void compact_rows_kernel(CompactArgs a) {
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kRowsPerWave;
-    if (row0 >= a.g.total_rows) return;
-    const unsigned* rc = a.rowcnt + (size_t)b * a.g.total_rows;
+    const int total_rows = a.g.total_rows, edge = a.g.edge;
+    const unsigned* fill = a.rowfill + (size_t)b * total_rows;
+    const uint32_t* lists = a.rowlist + (size_t)b * total_rows * kRowListCap;
+    const uint8_t* smap = a.smap + (size_t)b * a.g.frame_bytes;
     slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity;
     uint32_t* kpxy = a.kpxy + (size_t)b * a.capacity;
-#pragma unroll 1
-    for (int k = 0; k < kRowsPerWave; k++) {
-        const int row = row0 + k;
-        if (row >= a.g.total_rows) break;
-        if (rc[row] == 0) continue;
-        const int l = level_of_row(a.g, row);
-        const LevelGeom& L = a.g.lv[l];
-        const int y = row - L.row_base;
-        const unsigned cut = (unsigned)a.sel[b].cut[l];
-        // keypoints of earlier rows of this level
-        unsigned before = 0;
-        for (int r = lane; r < y; r += 64) before += rc[L.row_base + r];
-        before = wave_sum(before);
-        unsigned base = (unsigned)a.sel[b].offset[l] + before;
-        const uint8_t* r = a.smap + (size_t)b * a.g.frame_bytes + L.off + (size_t)y * L.pitch;
-        for (int xb = 0; xb < L.pitch; xb += 256) {
-            const int x = xb + 4 * lane;
-            uint32_t v = 0;
-            if (x < L.pitch) v = *reinterpret_cast<const uint32_t*>(r + x);
-            unsigned c = 0;
+    constexpr int kRegs = 16;             // list entries held in registers per row
+    constexpr unsigned kNone = 0xffffffffu;
+    const int l = my_level;
+    const LevelGeom& L = a.g.lv[l];
+    const unsigned cut = (unsigned)s_cut[l];
+    int base = 0;                         // keypoints of lower levels and of earlier passes
+    for (int i = 0; i < l; i++) base += s_cnt[i];
+    // One image row per thread and pass, rows inside the border only.
+    const int y_begin = edge, y_end = (cut < 256) ? L.h - edge : edge;
+    for (int y0 = y_begin; y0 < y_end; y0 += 1024) {
+        const int y = y0 + (int)threadIdx.x;
+        const int row = L.row_base + y;
+        unsigned n = 0;
+        if (y < y_end) n = fill[row];
+        const bool in_regs = n > 0 && n <= (unsigned)min(a.g.rowcap, kRegs);
+        const bool in_list = n > (unsigned)kRegs && n <= (unsigned)a.g.rowcap;
+        const bool dense = n > (unsigned)a.g.rowcap;
+        // sort key x << 8 | score of the kept entries; x is unique within a row
+        unsigned key[kRegs];
+        int cnt = 0;
+        if (in_regs) {
+            const uint32_t* e = lists + (size_t)row * kRowListCap;
 #pragma unroll
-            for (int j = 0; j < 4; j++) c += ((v >> (8 * j)) & 255u) >= cut;
-            if (__ballot(c != 0) == 0) continue;
-            // exclusive prefix of c over lanes
-            unsigned inc = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                unsigned nn = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += nn;
-            }
-            unsigned idx = base + inc - c;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const unsigned s = (v >> (8 * j)) & 255u;
-                if (s >= cut) {
-                    if (idx < (unsigned)a.capacity) {
-                        slam_amd_keypoint q;
-                        q.x = (float)(x + j);
-                        q.y = (float)y;
-                        q.size = L.size;
-                        q.angle = -1.f;
-                        q.response = (float)s;
-                        q.octave = l;
-                        q.class_id = -1;
-                        kp[idx] = q;
-                        kpxy[idx] = (uint32_t)(x + j) | ((uint32_t)y << 14) | ((uint32_t)l << 28);
-                    }
-                    idx++;
+            for (int i = 0; i < kRegs; i++) {
+                key[i] = kNone;
+                if ((unsigned)i < n) {
+                    const unsigned v = e[i], sc = v >> 16;
+                    if (sc >= cut) { key[i] = ((v & 0xffffu) << 8) | sc; cnt++; }
                 }
             }
-            base += __shfl(inc, 63, 64);
+        } else if (in_list) {
+            const uint32_t* e = lists + (size_t)row * kRowListCap;
+            for (unsigned i = 0; i < n; i++) cnt += (e[i] >> 16) >= cut;
+        } else if (dense) {
+            const uint8_t* r = smap + L.off + (size_t)y * L.pitch;
+            for (int x = edge; x < L.w - edge; x++) cnt += r[x] >= cut;
         }
+        // exclusive scan of the counts over the workgroup
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += v;
+        }
+        __syncthreads();                  // s_wave of the previous pass has been read
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        int pos = base + inc - cnt, pass_total = 0;
+        for (int w = 0; w < 16; w++) {
+            const int v = s_wave[w];
+            if (w < wave) pos += v;
+            pass_total += v;
+        }
+        base += pass_total;
+        if (cnt == 0) continue;
+        auto emit = [&](unsigned x, unsigned sc) {
+            if (pos < a.capacity) {
+                slam_amd_keypoint q;
+                q.x = (float)x;
+                q.y = (float)y;
+                q.size = L.size;
+                q.angle = -1.f;
+                q.response = (float)sc;
+                q.octave = l;
+                q.class_id = -1;
+                kp[pos] = q;
+                kpxy[pos] = x | ((uint32_t)y << 14) | ((uint32_t)l << 28);
+            }
+            pos++;
+        };
+        if (in_regs) {
+            // ascending x by repeated minimum over the register keys
+            for (int c = 0; c < cnt; c++) {
+                unsigned m = kNone;
+#pragma unroll
+                for (int i = 0; i < kRegs; i++) m = min(m, key[i]);
+#pragma unroll
+                for (int i = 0; i < kRegs; i++) if (key[i] == m) key[i] = kNone;
+                emit(m >> 8, m & 255u);
+            }
+        } else if (in_list) {
+            const uint32_t* e = lists + (size_t)row * kRowListCap;
+            int last = -1;
+            for (int c = 0; c < cnt; c++) {
+                unsigned bestx = kNone, bests = 0;
+                for (unsigned i = 0; i < n; i++) {
+                    const unsigned v = e[i], x = v & 0xffffu, sc = v >> 16;
+                    if (sc >= cut && (int)x > last && x < bestx) { bestx = x; bests = sc; }
+                }
+                emit(bestx, bests);
+                last = (int)bestx;
+            }
+        } else {
+            const uint8_t* r = smap + L.off + (size_t)y * L.pitch;
+            for (int x = edge; x < L.w - edge; x++) {
+                const unsigned sc = r[x];
+                if (sc >= cut) emit((unsigned)x, sc);
+            }
+        }
+    }
+    // the workgroup of the top level has every level's count: it publishes the totals
+    if (threadIdx.x == 0 && my_level == a.g.nlevels - 1) {
+        FrameSelect fs;
+        int acc = 0;
+        for (int i = 0; i < kMaxLevels; i++) {
+            const bool on = i < a.g.nlevels;
+            fs.cut[i] = on ? s_cut[i] : 256;
+            fs.count[i] = on ? s_cnt[i] : 0;
+            fs.offset[i] = acc;
+            acc += fs.count[i];
+        }
+        fs.total = acc;
+        fs.pad[0] = fs.pad[1] = fs.pad[2] = 0;
+        a.sel[b] = fs;
+        if (a.d_count) a.d_count[b] = acc;
     }
 }
 
@@ -636,11 +646,16 @@ constexpr int kURad = 15, kURows = 31, kUPitch = 36;   // 31 columns + up to 3 a
 constexpr int kBRad = 18, kBRows = 37, kBPitch = 40;   // 37 columns + up to 3 alignment bytes
 constexpr int kWaveLds = kURows * kUPitch + kBRows * kBPitch;  // 2596
 
-__constant__ int8_t c_pattern[256 * 4] = {
+__constant__ __align__(16) int8_t c_pattern[256 * 4] = {
 #include "orb_pattern_31.inc"
 };
 
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// Half-width of row |v| of the radius-15 disc, 4 bits per row:
+// 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3 for |v| = 0 .. 15.
+__device__ __forceinline__ int disc_half_width(int av) {
+    const unsigned long long packed = 0x3689ABCDDEEEFFFFull;
+    return (int)((packed >> (4 * av)) & 15u);
+}
 
 // Copies rows [y - R, y + R] x columns [x - R, x + R] of img into LDS.  Returns
 // the column shift: patch column c of row r is at dst[r * PITCH + shift + c].
@@ -680,6 +695,10 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
     if (i >= n) return;               // waves are independent: no workgroup barrier below
     uint8_t* s_u = s_all + wave * kWaveLds;
     uint8_t* s_b = s_u + kURows * kUPitch;
+    // the lane's four pattern rows (pair p = 64*k + lane), fetched ahead of everything else
+    uint32_t pat[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const uint32_t*>(c_pattern)[64 * k + lane];
 
     slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity + i;
     const uint32_t xy = a.kpxy[(size_t)b * a.capacity + i];
@@ -716,7 +735,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
             // half 0: v = -15 + vv (v in [-15, 0]); half 1: v = 1 + vv (v in [1, 16], 16 unused)
             const int v = half ? (1 + vv) : (-15 + vv);
             const int av = v < 0 ? -v : v;
-            if (av <= 15 && (lane & 31) < 31 && u >= -c_umax[av] && u <= c_umax[av]) {
+            const int hw = disc_half_width(av & 15);
+            if (av <= 15 && (lane & 31) < 31 && u >= -hw && u <= hw) {
                 const int val = ctr[v * kUPitch + u];
                 m10 += u * val;
                 m01 += v * val;
@@ -738,8 +758,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
     unsigned long long* out = reinterpret_cast<unsigned long long*>(a.desc + ((size_t)b * a.capacity + i) * 32);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int8_t* pp = c_pattern + (64 * k + lane) * 4;
-        const float px0 = (float)pp[0], py0 = (float)pp[1], px1 = (float)pp[2], py1 = (float)pp[3];
+        const float px0 = (float)(int8_t)(pat[k] & 255u), py0 = (float)(int8_t)((pat[k] >> 8) & 255u);
+        const float px1 = (float)(int8_t)((pat[k] >> 16) & 255u), py1 = (float)(int8_t)(pat[k] >> 24);
         const int ix0 = SA_RINT_I(SA_FSUB(SA_FMUL(px0, ca), SA_FMUL(py0, sb_)));
         const int iy0 = SA_RINT_I(SA_FADD(SA_FMUL(px0, sb_), SA_FMUL(py0, ca)));
         const int ix1 = SA_RINT_I(SA_FSUB(SA_FMUL(px1, ca), SA_FMUL(py1, sb_)));
@@ -774,22 +794,8 @@ int launch_fast(const FastArgs& a, int batch, hipStream_t st) {
     return SLAM_AMD_OK;
 }
 
-int launch_select(const SelectArgs& a, int batch, hipStream_t st) {
-    hipLaunchKernelGGL(select_levels_kernel, dim3(batch), dim3(256), 0, st, a);
-    SA_HIP(hipGetLastError());
-    return SLAM_AMD_OK;
-}
-
-int launch_count_rows(const CompactArgs& a, int batch, hipStream_t st) {
-    dim3 grid(div_up(a.g.total_rows, 4 * kRowsPerWave), batch);
-    hipLaunchKernelGGL(count_rows_kernel, grid, dim3(256), 0, st, a);
-    SA_HIP(hipGetLastError());
-    return SLAM_AMD_OK;
-}
-
-int launch_compact_rows(const CompactArgs& a, int batch, hipStream_t st) {
-    dim3 grid(div_up(a.g.total_rows, 4 * kRowsPerWave), batch);
-    hipLaunchKernelGGL(compact_rows_kernel, grid, dim3(256), 0, st, a);
+int launch_select_compact(const SelectCompactArgs& a, int batch, hipStream_t st) {
+    hipLaunchKernelGGL(select_compact_kernel, dim3(batch * a.g.nlevels), dim3(1024), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }

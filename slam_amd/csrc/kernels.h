@@ -29,20 +29,18 @@ struct FastArgs {
     uint8_t* smap;        // survivor map, same geometry as pyr (level 0 included)
     uint8_t* blur;        // blurred levels, same geometry as pyr (level 0 included)
     unsigned* hist;       // [batch][nlevels][256]
+    unsigned* rowfill;    // [batch][total_rows] survivors appended to each row's list
+    uint32_t* rowlist;    // [batch][total_rows][kRowListCap]
     PyrGeom g;
 };
 
-struct SelectArgs {
+struct SelectCompactArgs {
     const unsigned* hist;
+    const unsigned* rowfill;
+    const uint32_t* rowlist;
+    const uint8_t* smap;       // dense fallback for rows whose list overflowed
     FrameSelect* sel;
-    int32_t* d_count;  // may be null
-    PyrGeom g;
-};
-
-struct CompactArgs {
-    const uint8_t* smap;
-    const FrameSelect* sel;
-    unsigned* rowcnt;          // [batch][total_rows]
+    int32_t* d_count;          // may be null
     slam_amd_keypoint* kp;     // [batch][capacity]
     uint32_t* kpxy;            // [batch][capacity]  x | y << 14 | level << 28
     int capacity;
@@ -121,9 +119,7 @@ struct DupArgs {
 
 int launch_resize(const ResizeArgs& a, int batch, hipStream_t st);
 int launch_fast(const FastArgs& a, int batch, hipStream_t st);
-int launch_select(const SelectArgs& a, int batch, hipStream_t st);
-int launch_count_rows(const CompactArgs& a, int batch, hipStream_t st);
-int launch_compact_rows(const CompactArgs& a, int batch, hipStream_t st);
+int launch_select_compact(const SelectCompactArgs& a, int batch, hipStream_t st);
 int launch_describe(const DescribeArgs& a, int batch, hipStream_t st);
 int launch_match(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st);
 int launch_match_pairs(MatchArgs a, int n_pairs, hipStream_t st);

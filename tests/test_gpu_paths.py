@@ -106,6 +106,18 @@ def test_extract_degenerate_images(oracle, capi):
     ex.close()
 
 
+def test_extract_row_list_overflow_falls_back_to_dense_rows(oracle, capi):
+    """Rows with more corner survivors than their sparse list holds take the dense path."""
+    img = synth.scene(400, 300, 43)
+    kp_o, d_o = oracle.detect_and_compute(oracle.params(nfeatures=800), img)
+    for entries in (0, 1, 2, 5, 64):
+        ex = capi.Extractor(capi.orb_params(nfeatures=800), 400, 300, max_batch=1, max_keypoints=4096)
+        ex.debug_set_row_list_capacity(entries)
+        kp, d = ex.extract(img)
+        ex.close()
+        assert kp.tobytes() == kp_o.tobytes() and np.array_equal(d, d_o), entries
+
+
 def test_extract_other_parameters(oracle, capi):
     img = synth.scene(400, 300, 41)
     for kw in (dict(nfeatures=700, scale_factor=1.5, nlevels=5), dict(nfeatures=300, scale_factor=2.0, nlevels=3),
