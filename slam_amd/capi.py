@@ -60,10 +60,11 @@ def lib():
     """Load libslam_amd.so; raises OSError if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("SLAM_AMD_LIB", LIB_PATH)   # override: experiments with other builds
+        if not os.path.exists(path):
             raise OSError("%s not found: build it with `make -C slam_amd/csrc` "
-                          "(or __graft_entry__.build())" % LIB_PATH)
-        l = C.CDLL(LIB_PATH)
+                          "(or __graft_entry__.build())" % path)
+        l = C.CDLL(path)
         l.slam_amd_status_string.restype = C.c_char_p
         l.slam_amd_last_error.restype = C.c_char_p
         l.slam_amd_fast_atan2.restype = C.c_float
