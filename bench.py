@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--capacity", type=int, default=4096)
     ap.add_argument("--pair-keyframes", type=int, default=1024)
     ap.add_argument("--pair-desc", type=int, default=2000)
-    ap.add_argument("--pair-chunks", type=int, default=8)
+    ap.add_argument("--pair-chunks", type=int, default=16)
     ap.add_argument("--no-pairs", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=60)
@@ -177,6 +177,7 @@ def main():
 
     # ---- latency of one frame at a time (batch 1), same context ----
     lat_ms = None
+    lat_graph_ms = None
     if rank == 0:
         for _ in range(3):
             ex.extract_batch_async(d_img, 1, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
@@ -191,6 +192,31 @@ def main():
                                       cnt_p + 4, d_out, d_nout, 300.0, -1.0, -1, stream)
             torch.cuda.synchronize()
         lat_ms = (time.perf_counter() - t1) / reps * 1e3
+        lat_graph_ms = None
+        if graph is not None:
+            try:
+                def one():
+                    ex.extract_batch_async(d_img, 1, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
+                    m.frame_match_batch_async(1, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
+                                              cnt_p + 4, d_out, d_nout, 300.0, -1.0, -1, stream)
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream())
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, stream=side):
+                    stream = side.cuda_stream
+                    one()
+                stream = torch.cuda.current_stream().cuda_stream
+                for _ in range(3):
+                    g1.replay()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    g1.replay()
+                    torch.cuda.synchronize()
+                lat_graph_ms = (time.perf_counter() - t1) / reps * 1e3
+            except Exception as e:
+                sys.stderr.write("batch-1 graph capture failed: %s\n" % e)
+                stream = torch.cuda.current_stream().cuda_stream
 
     # ---- roofline of the dominant kernel (algorithmic bytes per launch / event time) ----
     px = pyramid_pixels(ws, hs)
@@ -226,6 +252,7 @@ def main():
     extra = {"launch_mode": "hip graph replay" if graph is not None else "eager",
              "ms_per_step_eager_with_stage_events": round(dt_eager / args.steps * 1e3, 4),
              "stage_us_per_launch": stage_us, "latency_ms_batch1": None if lat_ms is None else round(lat_ms, 4),
+             "latency_ms_batch1_graph": None if lat_graph_ms is None else round(lat_graph_ms, 4),
              "keypoints_per_frame": round(K, 1), "matches_per_frame": round(float(nmatch.mean()), 1)}
     if not args.no_pairs:
         extra["pairs"] = run_pairs(args, torch, dist, capi, synth, m, dev, rank, world, barrier)
@@ -413,10 +440,23 @@ def cpu_baseline(args, synth, seq):
         oracle.match_gated(prev[1], prev[0], cur[1], cur[0], 300.0, -1.0, -1)
         prev = cur
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same %dx%d / %d-feature stream: extract + brute-force match vs previous "
-                      "frame, CPU oracle (oracle/orb_oracle.c, gcc -O2, 1 thread)" %
-                      (n, args.width, args.height, args.nfeatures)}
+    out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of the same %dx%d / %d-feature stream: extract + brute-force match vs previous "
+                     "frame, CPU oracle (oracle/orb_oracle.c, gcc -O2, 1 thread as the reference runs)" %
+                     (n, args.width, args.height, args.nfeatures)}
+    # the same oracle with OpenMP over frames (extraction) and queries (matching)
+    threads = oracle.max_threads()
+    if threads > 1:
+        m = 4 * threads
+        frames = np.stack([seq[i % len(seq)] for i in range(m + 1)])
+        t0 = time.perf_counter()
+        res = oracle.detect_and_compute_batch(po, frames)
+        for i in range(m):
+            oracle.match_gated_mt(res[i][1], res[i][0], res[i + 1][1], res[i + 1][0], 300.0, -1.0, -1)
+        dt = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(m / dt, 3), "unit": "frames/s", "cores": threads,
+                            "sample": "%d frames, OpenMP over frames and queries" % m}
+    return out
 
 
 if __name__ == "__main__":

@@ -12,6 +12,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 static const int8_t k_pattern[256 * 4] = {
 #include "orb_pattern_31.inc"
@@ -464,6 +467,56 @@ int orc_detect_and_compute(const orc_params* p, const uint8_t* img, int w, int h
     return ORC_OK;
 }
 
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int orc_detect_and_compute_batch(const orc_params* p, const uint8_t* imgs, int n_frames, size_t frame_pitch,
+                                 int w, int h, int stride, orc_keypoint* kps, uint8_t* desc,
+                                 int capacity, int* counts) {
+    if (!imgs || !kps || !desc || !counts || n_frames < 0) return ORC_ERR_ARG;
+    int rc_all = ORC_OK;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int f = 0; f < n_frames; f++) {
+        int rc = orc_detect_and_compute(p, imgs + (size_t)f * frame_pitch, w, h, stride,
+                                        kps + (size_t)f * capacity, desc + (size_t)f * capacity * 32,
+                                        capacity, &counts[f]);
+        if (rc != ORC_OK) {
+#pragma omp critical
+            rc_all = rc;
+        }
+    }
+    return rc_all;
+}
+
+int orc_match_gated_mt(const uint8_t* qd, const orc_keypoint* qkp, int nq,
+                       const uint8_t* td, const orc_keypoint* tkp, int nt,
+                       float max_dist, float area, int max_level,
+                       orc_dmatch* out, int* n_out) {
+    if (!n_out || nq < 0 || nt < 0) return ORC_ERR_ARG;
+    /* one record per query (trainIdx -1 = none), compacted afterwards in query order */
+    orc_dmatch* tmp = (orc_dmatch*)malloc(sizeof(orc_dmatch) * (size_t)(nq > 0 ? nq : 1));
+    if (!tmp) return ORC_ERR_NOMEM;
+#pragma omp parallel for schedule(static)
+    for (int q = 0; q < nq; q++) {
+        int n = 0;
+        orc_dmatch one;
+        orc_match_gated(qd + (size_t)q * 32, qkp + q, 1, td, tkp, nt, max_dist, area, max_level, &one, &n);
+        tmp[q].trainIdx = -1;
+        if (n) { tmp[q] = one; tmp[q].queryIdx = q; }
+    }
+    int m = 0;
+    for (int q = 0; q < nq; q++)
+        if (tmp[q].trainIdx >= 0) out[m++] = tmp[q];
+    free(tmp);
+    *n_out = m;
+    return ORC_OK;
+}
+
 int orc_hamming256(const uint8_t* a, const uint8_t* b) {
     int d = 0;
     for (int i = 0; i < 32; i++) {
@@ -545,6 +598,68 @@ int orc_match_gated(const uint8_t* qd, const orc_keypoint* qkp, int nq,
             out[m].queryIdx = q; out[m].trainIdx = best_t; out[m].imgIdx = 0; out[m].distance = (float)best;
             m++;
         }
+    }
+    *n_out = m;
+    return ORC_OK;
+}
+
+/* Three fullest bins, scanned in ascending bin order with strict comparisons, as
+ * ORB-SLAM's ComputeThreeMaxima does; a bin below a tenth of the fullest is dropped. */
+static void three_maxima(const int* histo, int len, int* i1, int* i2, int* i3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    *i1 = *i2 = *i3 = -1;
+    for (int i = 0; i < len; i++) {
+        const int s = histo[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *i3 = *i2; *i2 = *i1; *i1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; *i3 = *i2; *i2 = i; }
+        else if (s > max3) { max3 = s; *i3 = i; }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { *i2 = -1; *i3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { *i3 = -1; }
+}
+
+static int rotation_bin(float angle_q, float angle_t, int len) {
+    float rot = angle_q - angle_t;
+    if (rot < 0.0f) rot += 360.0f;
+    const float factor = (float)len / 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin >= len) bin = 0;
+    return bin;
+}
+
+int orc_match_gated_ex(const uint8_t* qd, const orc_keypoint* qkp, int nq,
+                       const uint8_t* td, const orc_keypoint* tkp, int nt,
+                       float max_dist, float area, int max_level,
+                       float ratio, int histo_length,
+                       orc_dmatch* out, int* n_out) {
+    if (!n_out || nq < 0 || nt < 0 || histo_length > 64) return ORC_ERR_ARG;
+    int m = 0;
+    for (int q = 0; q < nq; q++) {
+        int best = 1 << 30, second = 1 << 30, best_t = -1;
+        for (int t = 0; t < nt; t++) {
+            if (!gate_pass(&qkp[q], &tkp[t], area, max_level)) continue;
+            const int d = orc_hamming256(qd + (size_t)q * 32, td + (size_t)t * 32);
+            if (d < best) { second = best; best = d; best_t = t; }
+            else if (d < second) second = d;
+        }
+        if (best_t < 0 || !((float)best <= max_dist)) continue;
+        if (ratio > 0.0f && second < (1 << 30) && !((float)best < ratio * (float)second)) continue;
+        out[m].queryIdx = q; out[m].trainIdx = best_t; out[m].imgIdx = 0; out[m].distance = (float)best;
+        m++;
+    }
+    if (histo_length > 0 && m > 0) {
+        int histo[64];
+        memset(histo, 0, sizeof histo);
+        for (int i = 0; i < m; i++)
+            histo[rotation_bin(qkp[out[i].queryIdx].angle, tkp[out[i].trainIdx].angle, histo_length)]++;
+        int i1, i2, i3;
+        three_maxima(histo, histo_length, &i1, &i2, &i3);
+        int k = 0;
+        for (int i = 0; i < m; i++) {
+            const int b = rotation_bin(qkp[out[i].queryIdx].angle, tkp[out[i].trainIdx].angle, histo_length);
+            if (b == i1 || b == i2 || b == i3) out[k++] = out[i];
+        }
+        m = k;
     }
     *n_out = m;
     return ORC_OK;

@@ -23,6 +23,7 @@
 #ifndef ORB_ORACLE_H
 #define ORB_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -107,6 +108,22 @@ int orc_brief_descriptor(const uint8_t* blurred, int stride, int cx, int cy, flo
 int orc_detect_and_compute(const orc_params* p, const uint8_t* img, int w, int h, int stride,
                            orc_keypoint* kps, uint8_t* desc, int capacity, int* n);
 
+/* n_frames independent frames of one size (frame f at imgs + f*frame_pitch), each
+ * processed by orc_detect_and_compute; frames run in parallel when the oracle is
+ * built with OpenMP.  Outputs are [n_frames][capacity] records; counts[f] = n. */
+int orc_detect_and_compute_batch(const orc_params* p, const uint8_t* imgs, int n_frames, size_t frame_pitch,
+                                 int w, int h, int stride, orc_keypoint* kps, uint8_t* desc,
+                                 int capacity, int* counts);
+
+/* orc_match_gated with the queries split over OpenMP threads (same result). */
+int orc_match_gated_mt(const uint8_t* qd, const orc_keypoint* qkp, int nq,
+                       const uint8_t* td, const orc_keypoint* tkp, int nt,
+                       float max_dist, float area, int max_level,
+                       orc_dmatch* out, int* n_out);
+
+/* Threads the two calls above use (1 when built without OpenMP). */
+int orc_max_threads(void);
+
 /* Hamming distance of two 32-byte rows. */
 int orc_hamming256(const uint8_t* a, const uint8_t* b);
 
@@ -123,6 +140,20 @@ int orc_match_gated(const uint8_t* qd, const orc_keypoint* qkp, int nq,
                     const uint8_t* td, const orc_keypoint* tkp, int nt,
                     float max_dist, float area, int max_level,
                     orc_dmatch* out, int* n_out);
+
+/* Options beyond the reference (it has neither; both default off in the library):
+ *  ratio > 0: Lowe's ratio test -- keep a match only if best < ratio * second best,
+ *    second best = next smallest distance among the train rows that pass the gates
+ *    (a query with a single candidate is kept);
+ *  histo_length > 0: rotation consistency as in ORB-SLAM -- bin = round((angle_q -
+ *    angle_t mod 360) * histo_length / 360) mod histo_length over all matches, keep
+ *    the matches of the three fullest bins (second / third only if >= 0.1 * first).
+ * Order of application: gates and max_dist, ratio, then rotation histogram. */
+int orc_match_gated_ex(const uint8_t* qd, const orc_keypoint* qkp, int nq,
+                       const uint8_t* td, const orc_keypoint* tkp, int nt,
+                       float max_dist, float area, int max_level,
+                       float ratio, int histo_length,
+                       orc_dmatch* out, int* n_out);
 
 /* Matcher::frameMatch (src/frame/matcher.cpp:15-55) on plain arrays: optional id
  * gather of the query side, match, remap of queryIdx. */

@@ -190,6 +190,29 @@ def detect_and_compute(p, img, capacity=None):
         return kps[:n.value].copy(), desc[:n.value].copy()
 
 
+def max_threads():
+    return int(lib().orc_max_threads())
+
+
+def detect_and_compute_batch(p, frames, capacity=4096):
+    """frames: [n, h, w] uint8.  Returns a list of (keypoints, descriptors); frames run in parallel."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, h, w = frames.shape
+    kps = np.zeros((n, capacity), KEYPOINT_DTYPE)
+    desc = np.zeros((n, capacity, 32), np.uint8)
+    counts = np.zeros(n, np.int32)
+    lib().orc_detect_and_compute_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                                   C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    rc = lib().orc_detect_and_compute_batch(C.cast(C.byref(p), C.c_void_p), _p(frames), n, h * w, w, h, w,
+                                            _p(kps), _p(desc), capacity, _p(counts))
+    if rc: raise ValueError("orc_detect_and_compute_batch rc=%d" % rc)
+    return [(kps[f, :counts[f]].copy(), desc[f, :counts[f]].copy()) for f in range(n)]
+
+
+def match_gated_mt(qd, qkp, td, tkp, max_dist=300.0, area=-1.0, max_level=4):
+    return _match(lib().orc_match_gated_mt, qd, qkp, td, tkp, max_dist, area, max_level)
+
+
 def hamming256(a, b):
     a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
     return int(lib().orc_hamming256(_p(a), _p(b)))
@@ -215,6 +238,19 @@ def radius_match_filter(qd, qkp, td, tkp, max_dist=300.0, area=-1.0, max_level=4
 
 def match_gated(qd, qkp, td, tkp, max_dist=300.0, area=-1.0, max_level=4):
     return _match(lib().orc_match_gated, qd, qkp, td, tkp, max_dist, area, max_level)
+
+
+def match_gated_ex(qd, qkp, td, tkp, max_dist=300.0, area=-1.0, max_level=4, ratio=0.0, histo_length=0):
+    qd = np.ascontiguousarray(qd, np.uint8).reshape(-1, 32)
+    td = np.ascontiguousarray(td, np.uint8).reshape(-1, 32)
+    qkp = np.ascontiguousarray(qkp, KEYPOINT_DTYPE); tkp = np.ascontiguousarray(tkp, KEYPOINT_DTYPE)
+    out = np.zeros(max(len(qd), 1), DMATCH_DTYPE)
+    n = C.c_int(0)
+    rc = lib().orc_match_gated_ex(_p(qd), _p(qkp), len(qd), _p(td), _p(tkp), len(td), C.c_float(max_dist),
+                                  C.c_float(area), int(max_level), C.c_float(ratio), int(histo_length),
+                                  _p(out), C.byref(n))
+    if rc: raise ValueError(rc)
+    return out[:n.value].copy()
 
 
 def frame_match(d1, kp1, d2, kp2, ids=None, max_dist=300.0, area=-1.0, max_level=4):
