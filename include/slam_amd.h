@@ -145,6 +145,22 @@ int slam_amd_matcher_destroy(slam_amd_matcher* m);
  * of a call) so that later _async calls of at most that size allocate nothing. */
 int slam_amd_matcher_reserve(slam_amd_matcher* m, size_t query_rows);
 
+/* Two post-filters the reference does not have (it calls radiusMatch and keeps the
+ * nearest gated row, src/frame/matcher.cpp:131-161); both are off after create and
+ * apply to every later frame_match call of this matcher, after the gates and max_dist:
+ *   ratio > 0         keep a match only if best < ratio * second best, the second best
+ *                     being the next smallest distance among the rows passing the gates
+ *                     (a query with one candidate is kept);
+ *   histo_length > 0  rotation consistency: histogram of (angle_query - angle_train)
+ *                     mod 360 over the matches of one call in histo_length (<= 64) bins,
+ *                     bin = round(diff * histo_length / 360) mod histo_length; matches
+ *                     outside the three fullest bins are dropped, and the second / third
+ *                     bin counts only if it holds at least a tenth of the first.
+ *                     Needs the keypoints of both sets.
+ * With ratio > 0 the scratch of slam_amd_matcher_reserve grows to 132 bytes per row.
+ * slam_amd_match_pairs_async returns SLAM_AMD_ERR_UNSUPPORTED while either is set. */
+int slam_amd_matcher_set_options(slam_amd_matcher* m, float ratio, int histo_length);
+
 /* Host, blocking.  For every query row (ascending), the train row of least
  * Hamming distance among those that pass the gates:
  *   distance <= max_dist                                   (matcher.cpp:43-45)

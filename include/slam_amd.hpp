@@ -284,6 +284,11 @@ public:
         return flag;
     }
 
+    // Not in the reference: Lowe's ratio test (nnRatio > 0) and the rotation-consistency
+    // histogram (histoLength > 0, e.g. 30) applied to every later match call; see
+    // slam_amd_matcher_set_options.  Both are off by default.
+    void setOptions(float nnRatio, int histoLength) { check(slam_amd_matcher_set_options(m_, nnRatio, histoLength)); }
+
     slam_amd_matcher* handle() const { return m_; }
 
 private:

@@ -441,6 +441,9 @@ struct slam_amd_matcher {
     int n_cu = 256;
     hipStream_t stream = nullptr;
     DevBuf best;                       // running keys of the async calls
+    DevBuf part;                       // per-split (best, second) keys when the ratio test is on
+    float ratio = 0.f;                 // options beyond the reference, both off by default
+    int histo_length = 0;
     DevBuf h_d1, h_k1, h_d2, h_k2, h_ids, h_xy, h_out, h_n, h_aux;  // host-call staging
 };
 
@@ -465,7 +468,7 @@ extern "C" int slam_amd_matcher_destroy(slam_amd_matcher* m) {
     if (!m) return SLAM_AMD_OK;
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
-    for (DevBuf* b : {&m->best, &m->h_d1, &m->h_k1, &m->h_d2, &m->h_k2, &m->h_ids, &m->h_xy, &m->h_out,
+    for (DevBuf* b : {&m->best, &m->part, &m->h_d1, &m->h_k1, &m->h_d2, &m->h_k2, &m->h_ids, &m->h_xy, &m->h_out,
                       &m->h_n, &m->h_aux})
         b->release();
     delete m;
@@ -475,7 +478,20 @@ extern "C" int slam_amd_matcher_destroy(slam_amd_matcher* m) {
 extern "C" int slam_amd_matcher_reserve(slam_amd_matcher* m, size_t query_rows) {
     if (!m) SA_FAIL(SLAM_AMD_ERR_ARG, "matcher is null");
     SA_HIP(hipSetDevice(m->device));
+    if (m->ratio > 0.f) {
+        int rc = m->part.reserve(query_rows * kMaxSecondSplits * sizeof(uint2));
+        if (rc) return rc;
+    }
     return m->best.reserve(query_rows * sizeof(unsigned));
+}
+
+extern "C" int slam_amd_matcher_set_options(slam_amd_matcher* m, float ratio, int histo_length) {
+    if (!m) SA_FAIL(SLAM_AMD_ERR_ARG, "matcher is null");
+    if (!(ratio >= 0.f)) SA_FAIL(SLAM_AMD_ERR_ARG, "ratio must be >= 0 (0 switches the test off)");
+    if (histo_length < 0 || histo_length > 64) SA_FAIL(SLAM_AMD_ERR_ARG, "histo_length must be in [0, 64]");
+    m->ratio = ratio;
+    m->histo_length = histo_length;
+    return SLAM_AMD_OK;
 }
 
 static int dmax_of(float max_dist) {
@@ -502,12 +518,23 @@ static int match_common(slam_amd_matcher* m, int batch,
         SA_FAIL(SLAM_AMD_ERR_ARG, "descriptor pointers must be 16-byte aligned");
     SA_HIP(hipSetDevice(m->device));
     const int nq = ids ? n_ids : n1;
-    const size_t rows = (size_t)batch * cap1;
-    int rc = m->best.reserve(std::max(rows, (size_t)1) * sizeof(unsigned));
-    if (rc) return rc;
-    {
+    const size_t rows = std::max((size_t)batch * cap1, (size_t)1);
+    const bool second = m->ratio > 0.f;
+    if (m->histo_length > 0 && nq > 0 && n2 > 0 && (!k1 || !k2))
+        SA_FAIL(SLAM_AMD_ERR_ARG, "the rotation-consistency option needs the keypoints of both sets");
+    const MatchPlan plan = plan_match(batch, nq, n2, m->n_cu, second);
+    int rc;
+    if (second) {
+        // every (query, split) cell is written by the kernel only where the split holds
+        // train rows, so the planes start out as "no match"
+        const size_t bytes = rows * plan.splits * sizeof(uint2);
+        if ((rc = m->part.reserve(bytes))) return rc;
         ProfScope ps(kStageMemset, st);
-        SA_HIP(hipMemsetAsync(m->best.p, 0xff, std::max(rows, (size_t)1) * sizeof(unsigned), st));
+        SA_HIP(hipMemsetAsync(m->part.p, 0xff, bytes, st));
+    } else {
+        if ((rc = m->best.reserve(rows * sizeof(unsigned)))) return rc;
+        ProfScope ps(kStageMemset, st);
+        SA_HIP(hipMemsetAsync(m->best.p, 0xff, rows * sizeof(unsigned), st));
     }
     MatchArgs a;
     memset(&a, 0, sizeof a);
@@ -516,10 +543,15 @@ static int match_common(slam_amd_matcher* m, int batch,
     a.ids = ids; a.n_ids = n_ids; a.q_xy = q_xy; a.cap1 = cap1; a.cap2 = cap2;
     a.area = area; a.max_level = max_level; a.dmax = dmax_of(max_dist);
     a.best = m->best.as<unsigned>();
-    { ProfScope ps(kStageMatch, st); if ((rc = launch_match(a, batch, nq, n2, m->n_cu, st))) return rc; }
+    a.part = second ? m->part.as<uint2>() : nullptr;
+    a.part_pitch = rows;
+    { ProfScope ps(kStageMatch, st); if ((rc = launch_match(a, plan, batch, st))) return rc; }
     FinalizeArgs f;
+    memset(&f, 0, sizeof f);
     f.best = m->best.as<unsigned>(); f.d_n1 = d_n1; f.n1 = n1; f.ids = ids; f.n_ids = n_ids;
     f.cap1 = cap1; f.dmax = a.dmax; f.out = d_out; f.n_out = d_n_out;
+    f.part = a.part; f.part_pitch = rows; f.splits = plan.splits;
+    f.ratio = m->ratio; f.histo_length = m->histo_length; f.qkp = k1; f.tkp = k2; f.cap2 = cap2;
     ProfScope ps(kStageFinalize, st);
     return launch_finalize(f, batch, st);
 }
@@ -616,6 +648,8 @@ extern "C" int slam_amd_match_pairs_async(slam_amd_matcher* m,
     const bool gated = (area != -1.f) || (max_level != -1);
     if (gated && !d_kp) SA_FAIL(SLAM_AMD_ERR_ARG, "keypoints are required when a gate is on");
     if (reinterpret_cast<uintptr_t>(d_desc) & 15) SA_FAIL(SLAM_AMD_ERR_ARG, "d_desc must be 16-byte aligned");
+    if (m->ratio > 0.f || m->histo_length > 0)
+        SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "match_pairs does not apply the ratio / rotation options; clear them first");
     SA_HIP(hipSetDevice(m->device));
     MatchArgs a;
     memset(&a, 0, sizeof a);

@@ -87,6 +87,18 @@ struct MatchArgs {
     int qblocks;                     // query blocks per problem
     int splits, batch;               // train splits per problem, problems per launch
     uint32_t* pair_out;              // [n_pairs][n_per]
+    // second-best mode (ratio test): every split stores (best key, second key)
+    uint2* part;                     // [splits][part_pitch], or null
+    size_t part_pitch;               // rows per split plane (batch * cap1)
+};
+
+constexpr int kMaxSecondSplits = 16;
+
+struct MatchPlan {
+    int q;        // queries per lane (1 or 2)
+    int qblocks;  // query blocks per problem
+    int splits;   // train splits per problem
+    int chunk;    // train rows per split
 };
 
 struct FinalizeArgs {
@@ -99,6 +111,15 @@ struct FinalizeArgs {
     int dmax;
     slam_amd_dmatch* out;     // [batch][cap1]
     int32_t* n_out;           // [batch]
+    // options beyond the reference
+    const uint2* part;        // per-split (best, second) keys, or null: read `best`
+    size_t part_pitch;
+    int splits;
+    float ratio;              // > 0: keep a match only if best < ratio * second best
+    int histo_length;         // > 0: rotation-consistency filter with that many bins (<= 64)
+    const slam_amd_keypoint* qkp;
+    const slam_amd_keypoint* tkp;
+    int cap2;
 };
 
 struct ProjectArgs {
@@ -121,7 +142,8 @@ int launch_resize(const ResizeArgs& a, int batch, hipStream_t st);
 int launch_fast(const FastArgs& a, int batch, hipStream_t st);
 int launch_select_compact(const SelectCompactArgs& a, int batch, hipStream_t st);
 int launch_describe(const DescribeArgs& a, int batch, hipStream_t st);
-int launch_match(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st);
+MatchPlan plan_match(int batch, int nq_bound, int nt_bound, int n_cu, bool second);
+int launch_match(MatchArgs a, const MatchPlan& p, int batch, hipStream_t st);
 int launch_match_pairs(MatchArgs a, int n_pairs, hipStream_t st);
 int launch_finalize(const FinalizeArgs& a, int batch, hipStream_t st);
 int launch_project(const ProjectArgs& a, hipStream_t st);

@@ -40,7 +40,9 @@ __device__ __forceinline__ int hamming256(const uint32_t (&q)[8], const uint4& a
 
 // Q queries per lane; AREA / LEVEL switch the window and octave gates on.
 // PAIRS: problem = keyframe pair, one split, result stored as (d << 16 | idx).
-template <int Q, bool AREA, bool LEVEL, bool PAIRS>
+// SECOND: also keep the second smallest key (for the ratio test); every split then
+// stores its (best, second) pair and the finalize kernel merges the splits.
+template <int Q, bool AREA, bool LEVEL, bool PAIRS, bool SECOND>
 __global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
     __shared__ uint4 s_desc[kTrainTile * 2];
     __shared__ float s_tx[AREA ? kTrainTile : 1];
@@ -81,11 +83,12 @@ __global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
     uint32_t q[Q][8];
     float qx[Q], qy[Q];
     bool qhigh[Q];
-    unsigned best[Q];
+    unsigned best[Q], second[Q];
 #pragma unroll
     for (int k = 0; k < Q; k++) {
         const int qi = qblock * (kMatchBlock * Q) + k * kMatchBlock + threadIdx.x;
         best[k] = kNoMatch;
+        second[k] = kNoMatch;
         qx[k] = qy[k] = 0.f;
         qhigh[k] = false;
         if (qi < nq) {
@@ -136,6 +139,18 @@ __global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
             return key;
         };
         int j = 0;
+        if (SECOND) {
+            // best <= second always holds, so the two smallest of {best, second, key}
+            // are min(best, key) and the median of the three
+            for (; j < tn; j++) {
+#pragma unroll
+                for (int k = 0; k < Q; k++) {
+                    const unsigned key = key_of(j, k);
+                    second[k] = min(max(best[k], key), second[k]);
+                    best[k] = min(best[k], key);
+                }
+            }
+        }
         // two train rows per trip: independent popcount chains and one 3-way minimum
         for (; j + 1 < tn; j += 2) {
 #pragma unroll
@@ -161,6 +176,8 @@ __global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
                 if ((int)d <= a.dmax) out = (d << 16) | t;
             }
             a.pair_out[(size_t)prob * a.n_per + qi] = out;
+        } else if (SECOND) {
+            a.part[(size_t)split * a.part_pitch + qbase + qi] = make_uint2(best[k], second[k]);
         } else {
             if (best[k] != kNoMatch) atomicMin(&a.best[qbase + qi], best[k]);
         }
@@ -168,11 +185,25 @@ __global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
 }
 
 // Keys -> cv::DMatch records in ascending query order, one workgroup per problem.
+// EX adds the two options the reference does not have: the ratio test on the
+// (best, second) pairs merged over the train splits, and the rotation-consistency
+// filter (histogram of angle differences, matches of the three fullest bins kept).
 
+__device__ __forceinline__ int rotation_bin(float angle_q, float angle_t, int len) {
+    float rot = __fsub_rn(angle_q, angle_t);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    const float factor = __fdiv_rn((float)len, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, factor));
+    if (bin >= len) bin = 0;
+    return bin;
+}
+
+template <bool EX>
 __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) {
     // Every thread owns a contiguous run of queries: count its matches, one
     // workgroup-wide exclusive scan of the 1024 counts, then write the run.
     __shared__ int s_wave[16];
+    __shared__ int s_hist[EX ? 64 : 1];
     const int prob = blockIdx.x;
     int n1 = a.n1;
     if (a.d_n1) n1 = min(n1, a.d_n1[prob]);
@@ -182,9 +213,62 @@ __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int per = (nq + 1023) / 1024;
     const int q0 = min((int)threadIdx.x * per, nq), q1 = min(q0 + per, nq);
-    auto valid = [&](unsigned key) { return key != kNoMatch && (int)(key >> kIdxBits) <= a.dmax; };
+    const bool rot_on = EX && a.histo_length > 0;
+    // key of query q after the distance bound and the ratio test, kNoMatch if rejected
+    auto accepted = [&](int q) -> unsigned {
+        unsigned b, s2 = kNoMatch;
+        if (EX && a.part) {
+            b = kNoMatch;
+            for (int sp = 0; sp < a.splits; sp++) {
+                const uint2 p = a.part[(size_t)sp * a.part_pitch + (size_t)prob * a.cap1 + q];
+                s2 = min(min(s2, p.y), max(b, p.x));
+                b = min(b, p.x);
+            }
+        } else {
+            b = best[q];
+        }
+        if (b == kNoMatch || (int)(b >> kIdxBits) > a.dmax) return kNoMatch;
+        if (EX && a.ratio > 0.f && s2 != kNoMatch) {
+            const float d1 = (float)(b >> kIdxBits), d2 = (float)(s2 >> kIdxBits);
+            if (!(d1 < __fmul_rn(a.ratio, d2))) return kNoMatch;
+        }
+        return b;
+    };
+    auto bin_of = [&](int q, unsigned key) -> int {
+        const size_t qrow = (size_t)prob * a.cap1 + (a.ids ? a.ids[q] : q);
+        const size_t trow = (size_t)prob * a.cap2 + (key & ((1u << kIdxBits) - 1));
+        return rotation_bin(a.qkp[qrow].angle, a.tkp[trow].angle, a.histo_length);
+    };
+    int i1 = -1, i2 = -1, i3 = -1;
+    if (rot_on) {
+        if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        for (int q = q0; q < q1; q++) {
+            const unsigned key = accepted(q);
+            if (key != kNoMatch) atomicAdd(&s_hist[bin_of(q, key)], 1);
+        }
+        __syncthreads();
+        // the three fullest bins, scanned in ascending order with strict comparisons
+        int max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < a.histo_length; i++) {
+            const int s = s_hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+            else if (s > max3) { max3 = s; i3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
+    }
+    auto kept = [&](int q) -> unsigned {
+        const unsigned key = accepted(q);
+        if (rot_on && key != kNoMatch) {
+            const int b = bin_of(q, key);
+            if (b != i1 && b != i2 && b != i3) return kNoMatch;
+        }
+        return key;
+    };
     int cnt = 0;
-    for (int q = q0; q < q1; q++) cnt += valid(best[q]);
+    for (int q = q0; q < q1; q++) cnt += kept(q) != kNoMatch;
     // exclusive scan over the workgroup
     int inc = cnt;
 #pragma unroll
@@ -202,8 +286,8 @@ __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) 
     }
     int pos = before + inc - cnt;
     for (int q = q0; q < q1; q++) {
-        const unsigned key = best[q];
-        if (!valid(key)) continue;
+        const unsigned key = kept(q);
+        if (key == kNoMatch) continue;
         slam_amd_dmatch r;
         r.queryIdx = a.ids ? a.ids[q] : q;
         r.trainIdx = (int)(key & ((1u << kIdxBits) - 1));
@@ -280,45 +364,50 @@ __global__ __launch_bounds__(256) void duplicate_kernel(DupArgs a) {
 // ---------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------
-template <int Q, bool PAIRS>
+template <int Q, bool PAIRS, bool SECOND>
 static void launch_match_t(const MatchArgs& a, dim3 grid, hipStream_t st) {
     const bool area = a.area != -1.f, level = a.max_level != -1;
-    if (area && level) hipLaunchKernelGGL((match_kernel<Q, true, true, PAIRS>), grid, dim3(kMatchBlock), 0, st, a);
-    else if (area) hipLaunchKernelGGL((match_kernel<Q, true, false, PAIRS>), grid, dim3(kMatchBlock), 0, st, a);
-    else if (level) hipLaunchKernelGGL((match_kernel<Q, false, true, PAIRS>), grid, dim3(kMatchBlock), 0, st, a);
-    else hipLaunchKernelGGL((match_kernel<Q, false, false, PAIRS>), grid, dim3(kMatchBlock), 0, st, a);
-}
-
-template <int Q>
-static int launch_match_q(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st) {
-    const int qblocks = div_up(nq_bound, kMatchBlock * Q);
-    // The bounds are capacities: the true counts live on the device and are often
-    // half of them, so aim for many small workgroups (those beyond the true counts
-    // exit at once) and merge the train splits with an atomic minimum.
-    constexpr int kGrain = 64;
-    int splits = div_up(n_cu * 16, qblocks * batch);
-    splits = max(1, min(splits, div_up(nt_bound, kGrain)));
-    a.chunk = div_up(div_up(nt_bound, splits), kGrain) * kGrain;
-    splits = div_up(nt_bound, a.chunk);
-    a.qblocks = qblocks;
-    a.splits = splits;
-    a.batch = batch;
-    const long long blocks = (long long)qblocks * splits * batch;
-    if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match: problem too large for one launch");
-    dim3 grid((unsigned)blocks);
-    launch_match_t<Q, false>(a, grid, st);
-    SA_HIP(hipGetLastError());
-    return SLAM_AMD_OK;
+    if (area && level) hipLaunchKernelGGL((match_kernel<Q, true, true, PAIRS, SECOND>), grid, dim3(kMatchBlock), 0, st, a);
+    else if (area) hipLaunchKernelGGL((match_kernel<Q, true, false, PAIRS, SECOND>), grid, dim3(kMatchBlock), 0, st, a);
+    else if (level) hipLaunchKernelGGL((match_kernel<Q, false, true, PAIRS, SECOND>), grid, dim3(kMatchBlock), 0, st, a);
+    else hipLaunchKernelGGL((match_kernel<Q, false, false, PAIRS, SECOND>), grid, dim3(kMatchBlock), 0, st, a);
 }
 
 // nq_bound / nt_bound: host-side upper bounds used to size the grid.
-int launch_match(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st) {
-    if (nq_bound <= 0 || nt_bound <= 0 || batch <= 0) return SLAM_AMD_OK;
+MatchPlan plan_match(int batch, int nq_bound, int nt_bound, int n_cu, bool second) {
+    MatchPlan p = {1, 0, 1, 0};
+    if (nq_bound <= 0 || nt_bound <= 0 || batch <= 0) return p;
     // two queries per lane once that still leaves enough workgroups to fill the chip
     const long long tiles = (long long)batch * div_up(nq_bound, kMatchBlock * 2) * div_up(nt_bound, kTrainTile);
-    if (tiles >= (long long)n_cu * 8)
-        return launch_match_q<2>(a, batch, nq_bound, nt_bound, n_cu, st);
-    return launch_match_q<1>(a, batch, nq_bound, nt_bound, n_cu, st);
+    p.q = tiles >= (long long)n_cu * 8 ? 2 : 1;
+    p.qblocks = div_up(nq_bound, kMatchBlock * p.q);
+    // The bounds are capacities: the true counts live on the device and are often
+    // half of them, so aim for many small workgroups (those beyond the true counts
+    // exit at once) and merge the train splits with an atomic minimum -- or, when
+    // second-best keys are kept, in the finalize kernel over at most 16 splits.
+    constexpr int kGrain = 64;
+    int splits = div_up(n_cu * 16, p.qblocks * batch);
+    splits = max(1, min(splits, div_up(nt_bound, kGrain)));
+    if (second) splits = min(splits, kMaxSecondSplits);
+    p.chunk = div_up(div_up(nt_bound, splits), kGrain) * kGrain;
+    p.splits = div_up(nt_bound, p.chunk);
+    return p;
+}
+
+int launch_match(MatchArgs a, const MatchPlan& p, int batch, hipStream_t st) {
+    if (p.qblocks <= 0 || batch <= 0) return SLAM_AMD_OK;
+    a.chunk = p.chunk;
+    a.qblocks = p.qblocks;
+    a.splits = p.splits;
+    a.batch = batch;
+    const long long blocks = (long long)p.qblocks * p.splits * batch;
+    if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match: problem too large for one launch");
+    dim3 grid((unsigned)blocks);
+    const bool second = a.part != nullptr;
+    if (p.q == 2) { if (second) launch_match_t<2, false, true>(a, grid, st); else launch_match_t<2, false, false>(a, grid, st); }
+    else { if (second) launch_match_t<1, false, true>(a, grid, st); else launch_match_t<1, false, false>(a, grid, st); }
+    SA_HIP(hipGetLastError());
+    return SLAM_AMD_OK;
 }
 
 int launch_match_pairs(MatchArgs a, int n_pairs, hipStream_t st) {
@@ -329,13 +418,15 @@ int launch_match_pairs(MatchArgs a, int n_pairs, hipStream_t st) {
     const long long blocks = (long long)a.qblocks * n_pairs;
     if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match_pairs: too many pairs for one launch");
     dim3 grid((unsigned)blocks);
-    launch_match_t<Q, true>(a, grid, st);
+    launch_match_t<Q, true, false>(a, grid, st);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }
 
 int launch_finalize(const FinalizeArgs& a, int batch, hipStream_t st) {
-    hipLaunchKernelGGL(finalize_matches_kernel, dim3(batch), dim3(1024), 0, st, a);
+    const bool ex = a.part != nullptr || a.histo_length > 0;
+    if (ex) hipLaunchKernelGGL(finalize_matches_kernel<true>, dim3(batch), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL(finalize_matches_kernel<false>, dim3(batch), dim3(1024), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }

@@ -39,3 +39,52 @@ def test_match_ids_and_maxdist(oracle, capi):
     assert np.array_equal(got, ref)
     assert len(got) > 0 and got["distance"].max() <= 40
     m.close()
+
+
+def _rotated_angles(k1, k2, src, seed, turn=37.0, noise=4.0, outliers=0.2):
+    """Query angles = matched train angle + a common turn + noise, a share of them random."""
+    rng = np.random.default_rng(seed)
+    a = k2["angle"][src] + turn + rng.normal(0, noise, len(k1))
+    bad = rng.random(len(k1)) < outliers
+    a[bad] = rng.uniform(0, 360, bad.sum())
+    k1["angle"] = np.mod(a, 360.0).astype(np.float32)
+
+
+@pytest.mark.parametrize("ratio,histo", [(0.7, 0), (0.95, 0), (0.0, 30), (0.8, 30), (0.9, 12), (1.5, 64)])
+@pytest.mark.parametrize("area,max_level", [(-1.0, -1), (60.0, 4)])
+def test_match_options_vs_oracle(oracle, capi, ratio, histo, area, max_level):
+    nq, nt, seed = 1300, 1900, 31
+    d1, k1, d2, k2 = _sets(nq, nt, seed)
+    src = np.random.default_rng(seed + 100).integers(0, nt, size=nq)
+    _rotated_angles(k1, k2, src, seed + 5)
+    # near-duplicate train rows, so that the ratio test has something to reject
+    d2[1::7] = synth.noisy_copy(d2[0::7][: len(d2[1::7])], 6, seed + 9)
+    m = capi.Matcher()
+    m.set_options(ratio, histo)
+    got = m.frame_match(d1, k1, d2, k2, max_dist=80.0, area=area, max_level=max_level)
+    ref = oracle.match_gated_ex(d1, k1, d2, k2, 80.0, area, max_level, ratio, histo)
+    plain = oracle.match_gated(d1, k1, d2, k2, 80.0, area, max_level)
+    assert np.array_equal(got, ref)
+    assert 0 < len(ref) <= len(plain)
+    if ratio in (0.7, 0.8) or histo in (30, 12):
+        assert len(ref) < len(plain)
+    # switching the options off restores the reference's behaviour
+    m.set_options(0.0, 0)
+    assert np.array_equal(m.frame_match(d1, k1, d2, k2, max_dist=80.0, area=area, max_level=max_level), plain)
+    m.close()
+
+
+def test_match_options_ids_and_errors(oracle, capi):
+    d1, k1, d2, k2 = _sets(700, 650, 41)
+    ids = np.arange(1, 700, 2, dtype=np.int32)
+    m = capi.Matcher()
+    m.set_options(0.85, 30)
+    got = m.frame_match(d1, k1, d2, k2, ids=ids, max_dist=300.0, area=-1.0, max_level=4)
+    ref = oracle.match_gated_ex(d1[ids], k1[ids], d2, k2, 300.0, -1.0, 4, 0.85, 30)
+    ref["queryIdx"] = ids[ref["queryIdx"]]
+    assert np.array_equal(got, ref)
+    with pytest.raises(capi.SlamAmdError):
+        m.set_options(-1.0, 0)
+    with pytest.raises(capi.SlamAmdError):
+        m.set_options(0.5, 65)
+    m.close()

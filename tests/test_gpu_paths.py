@@ -239,6 +239,21 @@ def test_frame_match_async_and_batch(oracle, capi):
             ref = oracle.match_gated(d1[:n1[b]], k1[:n1[b]], d2[:n2[b]], k2[:n2[b]], 300.0, area, lvl)
             assert int(nout[b].item()) == len(ref)
             assert res[b * CAP: b * CAP + len(ref)].tobytes() == ref.tobytes(), (b, area)
+    # the two optional post-filters on the batched device path
+    m.set_options(0.9, 30)
+    m.reserve(B * CAP)
+    m.frame_match_batch_async(B, D1, K1, CAP, N1, D2, K2, CAP, N2, out, nout, 300.0, 80.0, 4, st)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy().view(capi.DMATCH_DTYPE)
+    for b in range(B):
+        d1, k1, d2, k2 = sets[b]
+        ref = oracle.match_gated_ex(d1[:n1[b]], k1[:n1[b]], d2[:n2[b]], k2[:n2[b]], 300.0, 80.0, 4, 0.9, 30)
+        assert int(nout[b].item()) == len(ref)
+        assert res[b * CAP: b * CAP + len(ref)].tobytes() == ref.tobytes(), b
+    with pytest.raises(capi.SlamAmdError):
+        m.match_pairs_async(D1, K1, B, CAP, torch.zeros((1, 2), dtype=torch.int32, device="cuda"), 1,
+                            torch.zeros((1, CAP), dtype=torch.int32, device="cuda"), 300.0, -1.0, -1, st)
+    m.set_options(0.0, 0)
     # single problem, device counts smaller than the bounds, id gather
     d1, k1, d2, k2 = sets[0]
     ids = np.arange(5, 400, 7, dtype=np.int32)

@@ -493,3 +493,38 @@ def test_duplicate_pairs(oracle):
             dist = math.sqrt(sum(float(p1[i, k] - p2[j, k]) ** 2 for k in range(3)))
             assert flag[i, j] == int(ham <= 100 and dist < 1e-2)
     assert flag[:5, :5].trace() == 5
+
+
+def test_ratio_and_rotation_options_known_answers(oracle):
+    """Hand-built case for the two options the reference does not have."""
+    kp = np.zeros(4, oracle.KEYPOINT_DTYPE)
+    tk = np.zeros(6, oracle.KEYPOINT_DTYPE)
+    td = np.zeros((6, 32), np.uint8)
+    qd = np.zeros((4, 32), np.uint8)
+    # train row t has its first t+1 bytes set: distance to the all-zero query = 8 * (t + 1)
+    for t in range(6):
+        td[t, : t + 1] = 0xFF
+    # query 0: zero -> best 8 (t0), second 16: ratio 0.5 rejects (8 < 8 false), 0.51 keeps
+    assert len(oracle.match_gated_ex(qd[:1], kp[:1], td, tk, 300.0, -1.0, -1, 0.5, 0)) == 0
+    got = oracle.match_gated_ex(qd[:1], kp[:1], td, tk, 300.0, -1.0, -1, 0.51, 0)
+    assert len(got) == 1 and got[0]["trainIdx"] == 0 and got[0]["distance"] == 8.0
+    # a single candidate is kept whatever the ratio
+    assert len(oracle.match_gated_ex(qd[:1], kp[:1], td[:1], tk[:1], 300.0, -1.0, -1, 0.01, 0)) == 1
+    # rotation histogram: queries 0..2 turn by 40 degrees, query 3 by 200: with 30 bins of
+    # 12 degrees the lone match is below a tenth of nothing (1 < 0.1 * 3 is false) -> kept;
+    # with eleven matches in the main bin it is dropped
+    nq = 12
+    kp = np.zeros(nq, oracle.KEYPOINT_DTYPE)
+    kp["angle"] = 40.0
+    kp["angle"][-1] = 200.0
+    qd = np.zeros((nq, 32), np.uint8)
+    got = oracle.match_gated_ex(qd, kp, td, tk, 300.0, -1.0, -1, 0.0, 30)
+    assert len(got) == 11 and 11 not in got["queryIdx"]
+    got = oracle.match_gated_ex(qd[-4:], kp[-4:], td, tk, 300.0, -1.0, -1, 0.0, 30)
+    assert len(got) == 4
+    # bin wrap: a difference of 359 degrees rounds to bin 30 -> bin 0, the bin of 1 degree
+    kp = np.zeros(12, oracle.KEYPOINT_DTYPE)
+    kp["angle"][:11] = 1.0
+    kp["angle"][11] = 359.0
+    got = oracle.match_gated_ex(np.zeros((12, 32), np.uint8), kp, td, tk, 300.0, -1.0, -1, 0.0, 30)
+    assert len(got) == 12
