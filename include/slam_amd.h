@@ -161,6 +161,12 @@ int slam_amd_matcher_reserve(slam_amd_matcher* m, size_t query_rows);
  * slam_amd_match_pairs_async returns SLAM_AMD_ERR_UNSUPPORTED while either is set. */
 int slam_amd_matcher_set_options(slam_amd_matcher* m, float ratio, int histo_length);
 
+/* Test hook.  With the window gate on (area != -1) large problems are matched after
+ * reordering both sets by grid cell, visiting only train tiles near each group of
+ * queries; the result is identical to the full sweep.  mode 0 chooses by size
+ * (queries x train rows >= 2^25), 1 forces the full sweep, 2 forces the cell-sorted path. */
+int slam_amd_matcher_debug_set_window_mode(slam_amd_matcher* m, int mode);
+
 /* Host, blocking.  For every query row (ascending), the train row of least
  * Hamming distance among those that pass the gates:
  *   distance <= max_dist                                   (matcher.cpp:43-45)

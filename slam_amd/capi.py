@@ -30,7 +30,7 @@ EXPORTS = [
     "slam_amd_extract", "slam_amd_extract_batch_async", "slam_amd_extractor_debug_level",
     "slam_amd_extractor_debug_blurred_level", "slam_amd_extractor_debug_set_row_list_capacity",
     "slam_amd_matcher_create", "slam_amd_matcher_destroy", "slam_amd_matcher_reserve",
-    "slam_amd_matcher_set_options",
+    "slam_amd_matcher_set_options", "slam_amd_matcher_debug_set_window_mode",
     "slam_amd_frame_match", "slam_amd_frame_match_async", "slam_amd_frame_match_batch_async",
     "slam_amd_match_pairs_async",
     "slam_amd_project_points", "slam_amd_project_points_async", "slam_amd_duplicate_pairs",
@@ -75,6 +75,7 @@ def lib():
         l.slam_amd_default_orb_params.restype = None
         l.slam_amd_matcher_reserve.argtypes = [C.c_void_p, C.c_size_t]
         l.slam_amd_matcher_set_options.argtypes = [C.c_void_p, C.c_float, C.c_int]
+        l.slam_amd_matcher_debug_set_window_mode.argtypes = [C.c_void_p, C.c_int]
         l.slam_amd_extract_batch_async.argtypes = [
             C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
             C.c_void_p, C.c_int, C.c_void_p]
@@ -255,6 +256,9 @@ class Matcher:
 
     def reserve(self, rows):
         check(lib().slam_amd_matcher_reserve(self._h, rows))
+
+    def debug_set_window_mode(self, mode):
+        check(lib().slam_amd_matcher_debug_set_window_mode(self._h, mode))
 
     def set_options(self, ratio=0.0, histo_length=0):
         """Ratio test and rotation-consistency filter (neither is in the reference; 0 = off)."""

@@ -442,6 +442,8 @@ struct slam_amd_matcher {
     hipStream_t stream = nullptr;
     DevBuf best;                       // running keys of the async calls
     DevBuf part;                       // per-split (best, second) keys when the ratio test is on
+    DevBuf sorted;                     // both sets in grid-cell order for windowed matching
+    int window_mode = 0;               // 0: choose by size, 1: always the full sweep, 2: always cell-sorted
     float ratio = 0.f;                 // options beyond the reference, both off by default
     int histo_length = 0;
     DevBuf h_d1, h_k1, h_d2, h_k2, h_ids, h_xy, h_out, h_n, h_aux;  // host-call staging
@@ -468,7 +470,7 @@ extern "C" int slam_amd_matcher_destroy(slam_amd_matcher* m) {
     if (!m) return SLAM_AMD_OK;
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
-    for (DevBuf* b : {&m->best, &m->part, &m->h_d1, &m->h_k1, &m->h_d2, &m->h_k2, &m->h_ids, &m->h_xy, &m->h_out,
+    for (DevBuf* b : {&m->best, &m->part, &m->sorted, &m->h_d1, &m->h_k1, &m->h_d2, &m->h_k2, &m->h_ids, &m->h_xy, &m->h_out,
                       &m->h_n, &m->h_aux})
         b->release();
     delete m;
@@ -483,6 +485,12 @@ extern "C" int slam_amd_matcher_reserve(slam_amd_matcher* m, size_t query_rows) 
         if (rc) return rc;
     }
     return m->best.reserve(query_rows * sizeof(unsigned));
+}
+
+extern "C" int slam_amd_matcher_debug_set_window_mode(slam_amd_matcher* m, int mode) {
+    if (!m || mode < 0 || mode > 2) SA_FAIL(SLAM_AMD_ERR_ARG, "mode must be 0, 1 or 2");
+    m->window_mode = mode;
+    return SLAM_AMD_OK;
 }
 
 extern "C" int slam_amd_matcher_set_options(slam_amd_matcher* m, float ratio, int histo_length) {
@@ -522,7 +530,13 @@ static int match_common(slam_amd_matcher* m, int batch,
     const bool second = m->ratio > 0.f;
     if (m->histo_length > 0 && nq > 0 && n2 > 0 && (!k1 || !k2))
         SA_FAIL(SLAM_AMD_ERR_ARG, "the rotation-consistency option needs the keypoints of both sets");
-    const MatchPlan plan = plan_match(batch, nq, n2, m->n_cu, second);
+    // With the window gate on and sets large enough to repay the reordering, both sets
+    // are sorted by grid cell and only nearby tiles are compared; same result.
+    bool windowed = area > 0.f && area <= 3.0e38f && nq > 0 && n2 > 0;
+    if (m->window_mode == 1) windowed = false;
+    else if (m->window_mode == 0) windowed = windowed && (long long)nq * n2 >= (1LL << 25);
+    MatchPlan plan = plan_match(batch, nq, n2, m->n_cu, second);
+    if (windowed) plan.splits = window_splits(batch, nq, n2, m->n_cu);
     int rc;
     if (second) {
         // every (query, split) cell is written by the kernel only where the split holds
@@ -536,21 +550,65 @@ static int match_common(slam_amd_matcher* m, int batch,
         ProfScope ps(kStageMemset, st);
         SA_HIP(hipMemsetAsync(m->best.p, 0xff, rows * sizeof(unsigned), st));
     }
-    MatchArgs a;
-    memset(&a, 0, sizeof a);
-    a.qdesc = d1; a.qkp = k1; a.d_n1 = d_n1; a.n1 = n1;
-    a.tdesc = d2; a.tkp = k2; a.d_n2 = d_n2; a.n2 = n2;
-    a.ids = ids; a.n_ids = n_ids; a.q_xy = q_xy; a.cap1 = cap1; a.cap2 = cap2;
-    a.area = area; a.max_level = max_level; a.dmax = dmax_of(max_dist);
-    a.best = m->best.as<unsigned>();
-    a.part = second ? m->part.as<uint2>() : nullptr;
-    a.part_pitch = rows;
-    { ProfScope ps(kStageMatch, st); if ((rc = launch_match(a, plan, batch, st))) return rc; }
+    const int dmax = dmax_of(max_dist);
+    if (windowed) {
+        SpatialSortArgs sa_;
+        memset(&sa_, 0, sizeof sa_);
+        sa_.qdesc = d1; sa_.qkp = k1; sa_.d_n1 = d_n1; sa_.n1 = n1; sa_.cap1 = cap1;
+        sa_.tdesc = d2; sa_.tkp = k2; sa_.d_n2 = d_n2; sa_.n2 = n2; sa_.cap2 = cap2;
+        sa_.ids = ids; sa_.n_ids = n_ids; sa_.q_xy = q_xy; sa_.area = area; sa_.max_level = max_level;
+        // one allocation: per set descriptors (32 B), positions (8 B), indices (4 B) per row
+        // and a box (16 B) per 64 rows
+        size_t off = 0;
+        size_t o_desc[2], o_xy[2], o_idx[2], o_box[2];
+        for (int s = 0; s < 2; s++) {
+            const int bound = s == 0 ? nq : n2;
+            sa_.scap[s] = div_up(bound, 64) * 64;
+            const size_t r = (size_t)batch * sa_.scap[s];
+            o_desc[s] = off; off += r * 32;
+            o_xy[s] = off; off += r * 8;
+            o_idx[s] = off; off += r * 4;
+            o_box[s] = off; off += (r / 64) * 16;
+            off = (off + 255) & ~(size_t)255;
+        }
+        if ((rc = m->sorted.reserve(off))) return rc;
+        uint8_t* basep = m->sorted.as<uint8_t>();
+        WindowMatchArgs w;
+        memset(&w, 0, sizeof w);
+        for (int s = 0; s < 2; s++) {
+            sa_.sdesc[s] = reinterpret_cast<uint4*>(basep + o_desc[s]);
+            sa_.sxy[s] = reinterpret_cast<float2*>(basep + o_xy[s]);
+            sa_.sidx[s] = reinterpret_cast<uint32_t*>(basep + o_idx[s]);
+            sa_.tile_box[s] = reinterpret_cast<float4*>(basep + o_box[s]);
+            w.sdesc[s] = sa_.sdesc[s]; w.sxy[s] = sa_.sxy[s]; w.sidx[s] = sa_.sidx[s]; w.scap[s] = sa_.scap[s];
+        }
+        w.tile_box = sa_.tile_box[1];
+        w.d_n1 = d_n1; w.n1 = n1; w.d_n2 = d_n2; w.n2 = n2; w.has_ids = ids != nullptr; w.n_ids = n_ids;
+        w.cap1 = cap1; w.area = area; w.max_level = max_level; w.batch = batch;
+        w.best = m->best.as<unsigned>();
+        w.part = second ? m->part.as<uint2>() : nullptr;
+        w.part_pitch = rows;
+        w.splits = plan.splits;
+        { ProfScope ps(kStageSpatialSort, st); if ((rc = launch_spatial_sort(sa_, batch, nq, n2, st))) return rc; }
+        { ProfScope ps(kStageMatchWindow, st); if ((rc = launch_match_window(w, batch, nq, st))) return rc; }
+    } else {
+        MatchArgs a;
+        memset(&a, 0, sizeof a);
+        a.qdesc = d1; a.qkp = k1; a.d_n1 = d_n1; a.n1 = n1;
+        a.tdesc = d2; a.tkp = k2; a.d_n2 = d_n2; a.n2 = n2;
+        a.ids = ids; a.n_ids = n_ids; a.q_xy = q_xy; a.cap1 = cap1; a.cap2 = cap2;
+        a.area = area; a.max_level = max_level; a.dmax = dmax;
+        a.best = m->best.as<unsigned>();
+        a.part = second ? m->part.as<uint2>() : nullptr;
+        a.part_pitch = rows;
+        ProfScope ps(kStageMatch, st);
+        if ((rc = launch_match(a, plan, batch, st))) return rc;
+    }
     FinalizeArgs f;
     memset(&f, 0, sizeof f);
     f.best = m->best.as<unsigned>(); f.d_n1 = d_n1; f.n1 = n1; f.ids = ids; f.n_ids = n_ids;
-    f.cap1 = cap1; f.dmax = a.dmax; f.out = d_out; f.n_out = d_n_out;
-    f.part = a.part; f.part_pitch = rows; f.splits = plan.splits;
+    f.cap1 = cap1; f.dmax = dmax; f.out = d_out; f.n_out = d_n_out;
+    f.part = second ? m->part.as<uint2>() : nullptr; f.part_pitch = rows; f.splits = plan.splits;
     f.ratio = m->ratio; f.histo_length = m->histo_length; f.qkp = k1; f.tkp = k2; f.cap2 = cap2;
     ProfScope ps(kStageFinalize, st);
     return launch_finalize(f, batch, st);
@@ -753,7 +811,7 @@ extern "C" int slam_amd_prof_collect(double* total_ms, int* calls, int n_stages)
 
 extern "C" const char* slam_amd_prof_stage_name(int stage) {
     static const char* names[kStageCount] = {"resize_level (all levels)", "fast_nms", "select_compact",
-        "(unused)", "(unused)", "describe", "match", "finalize_matches", "match_pairs", "memset"};
+        "spatial_sort", "match_window", "describe", "match", "finalize_matches", "match_pairs", "memset"};
     return (stage >= 0 && stage < kStageCount) ? names[stage] : "";
 }
 

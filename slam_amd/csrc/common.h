@@ -63,7 +63,7 @@ struct FrameSelect {
 
 // Optional per-stage timing with HIP events on the stream the kernels run on.
 enum Stage {
-    kStageResize = 0, kStageFast, kStageSelect, kStageCountRows, kStageCompactRows, kStageDescribe,  // Select = select_compact; the two row stages are unused
+    kStageResize = 0, kStageFast, kStageSelect, kStageSpatialSort, kStageMatchWindow, kStageDescribe,
     kStageMatch, kStageFinalize, kStageMatchPairs, kStageMemset, kStageCount
 };
 void prof_mark(int stage, bool begin, hipStream_t st);

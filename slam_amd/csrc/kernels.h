@@ -101,6 +101,41 @@ struct MatchPlan {
     int chunk;    // train rows per split
 };
 
+// Reordering of both sets of a windowed match by grid cell (set 0 = queries, 1 = train).
+struct SpatialSortArgs {
+    const uint8_t* qdesc; const slam_amd_keypoint* qkp; const int32_t* d_n1; int n1; int cap1;
+    const uint8_t* tdesc; const slam_amd_keypoint* tkp; const int32_t* d_n2; int n2; int cap2;
+    const int32_t* ids; int n_ids;
+    const float* q_xy;
+    float area;               // > 0 and finite
+    int max_level;
+    uint4* sdesc[2];          // [batch][scap][2]  descriptors in cell order
+    float2* sxy[2];           // [batch][scap]     positions
+    uint32_t* sidx[2];        // [batch][scap]     original index | (octave > max_level) << 31
+    float4* tile_box[2];      // [batch][scap/64]  xmin, xmax, ymin, ymax of every 64-row tile (set 1 only)
+    int scap[2];              // rows per problem in the sorted arrays, multiples of 64
+    int qchunks;              // 4096-row chunks of the query set (set by the launcher)
+};
+
+struct WindowMatchArgs {
+    const uint4* sdesc[2];
+    const float2* sxy[2];
+    const uint32_t* sidx[2];
+    const float4* tile_box;   // of the train set
+    int scap[2];
+    const int32_t* d_n1; int n1;
+    const int32_t* d_n2; int n2;
+    int has_ids, n_ids;
+    int cap1;                 // rows between consecutive problems in best / part
+    float area;
+    int max_level;
+    int batch;
+    int splits;               // train tiles are dealt round-robin to this many waves per query tile
+    unsigned* best;           // [batch][cap1], merged with atomicMin
+    uint2* part;              // [splits][part_pitch] (best, second) when the ratio test is on, else null
+    size_t part_pitch;
+};
+
 struct FinalizeArgs {
     const unsigned* best;
     const int32_t* d_n1;
@@ -145,6 +180,9 @@ int launch_describe(const DescribeArgs& a, int batch, hipStream_t st);
 MatchPlan plan_match(int batch, int nq_bound, int nt_bound, int n_cu, bool second);
 int launch_match(MatchArgs a, const MatchPlan& p, int batch, hipStream_t st);
 int launch_match_pairs(MatchArgs a, int n_pairs, hipStream_t st);
+int launch_spatial_sort(SpatialSortArgs a, int batch, int nq_bound, int nt_bound, hipStream_t st);
+int window_splits(int batch, int nq_bound, int nt_bound, int n_cu);
+int launch_match_window(const WindowMatchArgs& a, int batch, int nq_bound, hipStream_t st);
 int launch_finalize(const FinalizeArgs& a, int batch, hipStream_t st);
 int launch_project(const ProjectArgs& a, hipStream_t st);
 int launch_duplicates(const DupArgs& a, hipStream_t st);

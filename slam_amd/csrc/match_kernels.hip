@@ -198,10 +198,11 @@ __device__ __forceinline__ int rotation_bin(float angle_q, float angle_t, int le
     return bin;
 }
 
+constexpr int kFinalRows = 8;                      // rows of 64 queries per wave and chunk
+constexpr int kFinalChunk = 16 * kFinalRows * 64;  // queries per chunk of the 16 waves
+
 template <bool EX>
 __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) {
-    // Every thread owns a contiguous run of queries: count its matches, one
-    // workgroup-wide exclusive scan of the 1024 counts, then write the run.
     __shared__ int s_wave[16];
     __shared__ int s_hist[EX ? 64 : 1];
     const int prob = blockIdx.x;
@@ -211,8 +212,6 @@ __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) 
     const unsigned* best = a.best + (size_t)prob * a.cap1;
     slam_amd_dmatch* out = a.out + (size_t)prob * a.cap1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per = (nq + 1023) / 1024;
-    const int q0 = min((int)threadIdx.x * per, nq), q1 = min(q0 + per, nq);
     const bool rot_on = EX && a.histo_length > 0;
     // key of query q after the distance bound and the ratio test, kNoMatch if rejected
     auto accepted = [&](int q) -> unsigned {
@@ -243,7 +242,7 @@ __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) 
     if (rot_on) {
         if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
         __syncthreads();
-        for (int q = q0; q < q1; q++) {
+        for (int q = threadIdx.x; q < nq; q += 1024) {
             const unsigned key = accepted(q);
             if (key != kNoMatch) atomicAdd(&s_hist[bin_of(q, key)], 1);
         }
@@ -267,35 +266,50 @@ __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) 
         }
         return key;
     };
-    int cnt = 0;
-    for (int q = q0; q < q1; q++) cnt += kept(q) != kNoMatch;
-    // exclusive scan over the workgroup
-    int inc = cnt;
+    // Chunks of kFinalChunk queries, kFinalRows rows of 64 consecutive queries per wave:
+    // keys are fetched once with coalesced loads and stay in registers; a ballot per
+    // row gives the counts, one pass over the 16 wave totals gives the wave's first
+    // output slot, and a lane's slot inside a row is the number of set bits below it,
+    // so the records of a row are written side by side.
+    int written = 0;  // matches of the chunks before this one (same in every thread)
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = 0; base < nq; base += kFinalChunk) {
+        unsigned key[kFinalRows];
+        unsigned long long mask[kFinalRows];
+        int wcount = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int n = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += n;
+        for (int k = 0; k < kFinalRows; k++) {
+            const int q = base + (wave * kFinalRows + k) * 64 + lane;
+            key[k] = q < nq ? kept(q) : kNoMatch;
+            mask[k] = __ballot(key[k] != kNoMatch);
+            wcount += __popcll(mask[k]);
+        }
+        __syncthreads();
+        if (lane == 0) s_wave[wave] = wcount;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < 16; w++) {
+            const int v = s_wave[w];
+            if (w < wave) before += v;
+            total += v;
+        }
+        int pos = written + before;
+#pragma unroll
+        for (int k = 0; k < kFinalRows; k++) {
+            if (key[k] != kNoMatch) {
+                const int q = base + (wave * kFinalRows + k) * 64 + lane;
+                slam_amd_dmatch r;
+                r.queryIdx = a.ids ? a.ids[q] : q;
+                r.trainIdx = (int)(key[k] & ((1u << kIdxBits) - 1));
+                r.imgIdx = 0;
+                r.distance = (float)(key[k] >> kIdxBits);
+                out[pos + __popcll(mask[k] & below)] = r;
+            }
+            pos += __popcll(mask[k]);
+        }
+        written += total;
     }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    int before = 0, total = 0;
-    for (int w = 0; w < 16; w++) {
-        const int v = s_wave[w];
-        if (w < wave) before += v;
-        total += v;
-    }
-    int pos = before + inc - cnt;
-    for (int q = q0; q < q1; q++) {
-        const unsigned key = kept(q);
-        if (key == kNoMatch) continue;
-        slam_amd_dmatch r;
-        r.queryIdx = a.ids ? a.ids[q] : q;
-        r.trainIdx = (int)(key & ((1u << kIdxBits) - 1));
-        r.imgIdx = 0;
-        r.distance = (float)(key >> kIdxBits);
-        out[pos++] = r;
-    }
-    if (threadIdx.x == 0) a.n_out[prob] = total;
+    if (threadIdx.x == 0) a.n_out[prob] = written;
 }
 
 // Pinhole projection with radial/tangential distortion, double arithmetic.

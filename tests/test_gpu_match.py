@@ -88,3 +88,56 @@ def test_match_options_ids_and_errors(oracle, capi):
     with pytest.raises(capi.SlamAmdError):
         m.set_options(0.5, 65)
     m.close()
+
+
+@pytest.mark.parametrize("nq,nt,area,max_level", [(1500, 1700, 50.0, 4), (1500, 1700, 12.5, -1), (70, 3000, 200.0, 3),
+                                                   (5000, 63, 30.0, 4), (1, 1, 5.0, -1), (2500, 2500, 1e9, 4)])
+def test_cell_sorted_window_match_equals_full_sweep(oracle, capi, nq, nt, area, max_level):
+    d1, k1, d2, k2 = _sets(nq, nt, 51)
+    ref = oracle.match_gated(d1, k1, d2, k2, 300.0, area, max_level)
+    m = capi.Matcher()
+    for mode in (2, 1, 0):
+        m.debug_set_window_mode(mode)
+        got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=area, max_level=max_level)
+        assert np.array_equal(got, ref), mode
+    m.close()
+
+
+def test_cell_sorted_window_match_odd_positions(oracle, capi):
+    """Positions that are NaN, infinite, huge, negative or all equal; ids and query positions."""
+    nq, nt = 900, 1100
+    d1, k1, d2, k2 = _sets(nq, nt, 61)
+    rng = np.random.default_rng(5)
+    k2["x"][rng.integers(0, nt, 20)] = np.nan
+    k2["y"][rng.integers(0, nt, 20)] = np.inf
+    k2["x"][rng.integers(0, nt, 20)] = -np.inf
+    k2["x"][:30] = 3.0e38
+    k2["y"][:30] = -3.0e38
+    q_xy = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    q_xy[rng.integers(0, nq, 30)] = np.nan
+    q_xy[rng.integers(0, nq, 30), 0] = np.inf
+    q_xy[:15] = (3.0e38, -3.0e38)          # coincide with the huge train positions: they must still match
+    q_xy[15:40] = (-250.0, -1000.5)
+    ids = rng.permutation(nq)[:700].astype(np.int32)
+    ids.sort()
+    qpos = q_xy[:len(ids)]
+    kq = k1[ids].copy(); kq["x"] = qpos[:, 0]; kq["y"] = qpos[:, 1]
+    m = capi.Matcher()
+    for area in (40.0, 1.0e30):
+        ref = oracle.match_gated(d1[ids], kq, d2, k2, 300.0, area, 4)
+        ref["queryIdx"] = ids[ref["queryIdx"]]
+        for mode in (2, 1):
+            m.debug_set_window_mode(mode)
+            got = m.frame_match(d1, k1, d2, k2, ids=ids, q_xy=qpos, max_dist=300.0, area=area, max_level=4)
+            assert np.array_equal(got, ref), (area, mode)
+    # every position identical
+    k1["x"] = k1["y"] = 7.0; k2["x"] = k2["y"] = 7.25
+    m.debug_set_window_mode(2)
+    got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=0.5, max_level=-1)
+    assert np.array_equal(got, oracle.match_gated(d1, k1, d2, k2, 300.0, 0.5, -1)) and len(got) == nq
+    # the options ride on the cell-sorted path as well
+    d1, k1, d2, k2 = _sets(nq, nt, 62)
+    m.set_options(0.9, 30)
+    got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=45.0, max_level=4)
+    assert np.array_equal(got, oracle.match_gated_ex(d1, k1, d2, k2, 300.0, 45.0, 4, 0.9, 30))
+    m.close()

@@ -209,10 +209,13 @@ def test_projection_windowed_match_20k_vs_4k(oracle, capi):
     ids = np.arange(20000, dtype=np.int32)
     m = capi.Matcher()
     got = m.frame_match(d1, k1, d2, k2, ids=ids, q_xy=q_xy, max_dist=300.0, area=50.0, max_level=4)
+    m.debug_set_window_mode(1)
+    full = m.frame_match(d1, k1, d2, k2, ids=ids, q_xy=q_xy, max_dist=300.0, area=50.0, max_level=4)
     m.close()
     kq = k1.copy(); kq["x"] = q_xy[:, 0]; kq["y"] = q_xy[:, 1]
     ref = oracle.match_gated(d1, kq, d2, k2, 300.0, 50.0, 4)
     assert got.tobytes() == ref.tobytes() and len(got) > 10000
+    assert full.tobytes() == ref.tobytes()
 
 
 def test_frame_match_async_and_batch(oracle, capi):
@@ -230,7 +233,8 @@ def test_frame_match_async_and_batch(oracle, capi):
     N1 = torch.tensor(n1, dtype=torch.int32, device="cuda"); N2 = torch.tensor(n2, dtype=torch.int32, device="cuda")
     out = torch.zeros(B * CAP * DM, dtype=torch.uint8, device="cuda")
     nout = torch.zeros(B, dtype=torch.int32, device="cuda")
-    for area, lvl in ((-1.0, -1), (80.0, 4)):
+    for area, lvl, mode in ((-1.0, -1, 0), (80.0, 4, 1), (80.0, 4, 2), (25.0, -1, 2)):
+        m.debug_set_window_mode(mode)
         m.frame_match_batch_async(B, D1, K1, CAP, N1, D2, K2, CAP, N2, out, nout, 300.0, area, lvl, st)
         torch.cuda.synchronize()
         res = out.cpu().numpy().view(capi.DMATCH_DTYPE)
@@ -238,7 +242,8 @@ def test_frame_match_async_and_batch(oracle, capi):
             d1, k1, d2, k2 = sets[b]
             ref = oracle.match_gated(d1[:n1[b]], k1[:n1[b]], d2[:n2[b]], k2[:n2[b]], 300.0, area, lvl)
             assert int(nout[b].item()) == len(ref)
-            assert res[b * CAP: b * CAP + len(ref)].tobytes() == ref.tobytes(), (b, area)
+            assert res[b * CAP: b * CAP + len(ref)].tobytes() == ref.tobytes(), (b, area, mode)
+    m.debug_set_window_mode(2)
     # the two optional post-filters on the batched device path
     m.set_options(0.9, 30)
     m.reserve(B * CAP)
@@ -254,6 +259,7 @@ def test_frame_match_async_and_batch(oracle, capi):
         m.match_pairs_async(D1, K1, B, CAP, torch.zeros((1, 2), dtype=torch.int32, device="cuda"), 1,
                             torch.zeros((1, CAP), dtype=torch.int32, device="cuda"), 300.0, -1.0, -1, st)
     m.set_options(0.0, 0)
+    m.debug_set_window_mode(0)
     # single problem, device counts smaller than the bounds, id gather
     d1, k1, d2, k2 = sets[0]
     ids = np.arange(5, 400, 7, dtype=np.int32)
