@@ -224,7 +224,9 @@ def main():
     K = float(counts.mean())
     alg_bytes = {
         "resize_level (all levels)": B * ((P - Ptop) + (P - P0)),
-        "fast_nms": B * P,
+        # the fused kernel covers two stages of the un-fused accounting:
+        # FAST (P read) + 7x7 blur (P read + P written)
+        "fast_nms": B * 3 * P,
         "describe": B * K * (749 + 512 + 28 + 32),
     }
     roofline = None
@@ -236,7 +238,8 @@ def main():
         if dom in alg_bytes:
             ach = alg_bytes[dom] / avg_s / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                        "traffic": pmc_traffic(dom, B, W, H),
                         "avg_launch_us": round(avg_s * 1e6, 2),
                         "algorithmic_bytes_per_launch": int(alg_bytes[dom])}
         else:
@@ -278,6 +281,23 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(line), flush=True)
+
+
+def pmc_traffic(kernel, batch, width, height):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, written by tools/summarize_profile.py from separate FETCH_SIZE
+    and WRITE_SIZE runs of this same command): 2 x FETCH_SIZE (gfx950 counts dword-per-lane
+    reads at half their bytes) + WRITE_SIZE.  None when no pass matches this batch and size."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    k = rec.get("kernels", {}).get(kernel.split(" ")[0])
+    if not k or rec.get("batch") != batch or rec.get("width") != width or rec.get("height") != height:
+        return None
+    return int(2 * k["fetch_size_kib"] * 1024 + k["write_size_kib"] * 1024)
 
 
 def run_pairs(args, torch, dist, capi, synth, m, dev, rank, world, barrier):

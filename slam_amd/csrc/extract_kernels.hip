@@ -201,16 +201,20 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     static_assert(kScPitch == kImgPitch, "score tile and image tile share one pitch");
     static_assert(kRowRows * kFastTileW * 2 <= 2 * kListBytes, "row-pass buffer must fit the scratch region");
 
-    const int b = blockIdx.y;
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  XCD k
+    // takes the k-th contiguous eighth of all (frame, tile) pairs, so tiles that share
+    // halo lines run on the same L2 instead of fetching them once per XCD.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int g = xcd * a.tiles_per_xcd + slot;
+    if (g >= a.tiles_all) return;
+    const int b = g / a.g.total_tiles;
+    const int ftile = g - b * a.g.total_tiles;
     int l = 0;
-    {
-        const int tile = blockIdx.x;
 #pragma unroll 1
-        for (int i = 1; i < a.g.nlevels; i++)
-            if (tile >= a.g.lv[i].tile_base) l = i;
-    }
+    for (int i = 1; i < a.g.nlevels; i++)
+        if (ftile >= a.g.lv[i].tile_base) l = i;
     const LevelGeom& L = a.g.lv[l];
-    const int tile = blockIdx.x - L.tile_base;
+    const int tile = ftile - L.tile_base;
     const int tyi = tile / L.tiles_x, txi = tile - tyi * L.tiles_x;
     const int x0 = txi * kFastTileW, y0 = tyi * kFastTileH;
     const int w = L.w, h = L.h;
@@ -787,8 +791,11 @@ int launch_resize(const ResizeArgs& a, int batch, hipStream_t st) {
     return SLAM_AMD_OK;
 }
 
-int launch_fast(const FastArgs& a, int batch, hipStream_t st) {
-    dim3 grid(a.g.total_tiles, batch);
+int launch_fast(const FastArgs& a0, int batch, hipStream_t st) {
+    FastArgs a = a0;
+    a.tiles_all = a.g.total_tiles * batch;
+    a.tiles_per_xcd = div_up(a.tiles_all, 8);
+    dim3 grid(a.tiles_per_xcd * 8);
     hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;

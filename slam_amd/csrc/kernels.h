@@ -31,6 +31,8 @@ struct FastArgs {
     unsigned* hist;       // [batch][nlevels][256]
     unsigned* rowfill;    // [batch][total_rows] survivors appended to each row's list
     uint32_t* rowlist;    // [batch][total_rows][kRowListCap]
+    int tiles_all;        // total_tiles * batch (set by the launcher)
+    int tiles_per_xcd;    // ceil(tiles_all / 8)
     PyrGeom g;
 };
 

@@ -25,14 +25,14 @@ if stats:
                                                       float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 trace = glob.glob(os.path.join(src, "trace", "*", "*kernel_trace.csv"))
 if trace:
-    # timed-region launches = the largest grid of each kernel (batch 32)
+    # timed-region launches = the largest grid of each kernel
     rows = list(csv.DictReader(open(trace[0])))
     byk = collections.defaultdict(list)
     for r in rows:
         g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) if "Grid_Size_X" in r else int(r.get("Grid_Size", 0))
         byk[kernel_short(r["Kernel_Name"])].append((g, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     out.append("")
-    out.append("== per kernel, launches with the largest grid only (the batch-32 steps of the timed region) ==")
+    out.append("== per kernel, launches with the largest grid only (the full-batch steps of the timed region) ==")
     out.append("%-62s %7s %12s" % ("kernel", "calls", "avg_us"))
     for k, v in sorted(byk.items(), key=lambda kv: -sum(t for g, t in kv[1])):
         gmax = max(g for g, t in v)
@@ -56,6 +56,37 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
             sel = [x for g, x in v if g == gmax]
             parts.append("%s=%.0f" % (c, sum(sel) / len(sel)))
         out.append("%-62s %s" % (k, "  ".join(parts)))
+# machine-readable PMC record for bench.py's roofline.traffic
+if len(sys.argv) > 2:
+    rec = {"kernels": {}}
+    vals = collections.defaultdict(dict)
+    for name, key in (("pmc_fetch", "fetch_size_kib"), ("pmc_write", "write_size_kib")):
+        files = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))
+        if not files:
+            continue
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(files[0])):
+            per[kernel_short(r["Kernel_Name"])].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+        for k, v in per.items():
+            if k.startswith("at::") or k.startswith("__amd") or not k:
+                continue
+            gmax = max(g for g, _ in v)
+            sel = [x for g, x in v if g == gmax]
+            short = k.replace("_kernel", "").split("<")[0]
+            if gmax >= vals[short].get("_grid_" + key, 0):   # template variants: keep the largest launch
+                vals[short][key] = sum(sel) / len(sel)
+                vals[short]["_grid_" + key] = gmax
+    rec["kernels"] = {k: {kk: vv for kk, vv in v.items() if not kk.startswith("_")} for k, v in vals.items()
+                      if "fetch_size_kib" in v and "write_size_kib" in v}
+    try:
+        line = json.loads(open(os.path.join(src, "trace_bench.json")).read().strip().splitlines()[-1])
+        rec["batch"] = line["config"]["frames_per_step_per_gpu"]
+        wl = line["config"]["workload"].split(" ")[0].split("x")
+        rec["width"], rec["height"] = int(wl[0]), int(wl[1])
+    except Exception:
+        pass
+    rec["source"] = "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs of bench.py; per launch, largest grid"
+    json.dump(rec, open(sys.argv[2], "w"), indent=1)
 for j in ("trace_bench.json",):
     p = os.path.join(src, j)
     if os.path.exists(p) and os.path.getsize(p):
