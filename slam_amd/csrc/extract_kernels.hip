@@ -639,23 +639,25 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs 
 }
 
 // ---------------------------------------------------------------------------
-// Describe: one wavefront per keypoint.  Two patches are staged in the wave's
-// LDS slice with aligned 4-byte loads: 31 x 31 of the unblurred level (intensity
-// centroid over the radius-15 disc, wave reduction) and 37 x 37 of the blurred
-// level (256 rotated rBRIEF comparisons, 4 per lane, assembled by ballot; the
-// rotated pattern reaches at most 18 pixels).  Keypoints lie >= 31 pixels from
-// the level border, so both patches are inside the level.
+// Describe: one single-wave workgroup per keypoint, so everything derived from the
+// keypoint index is scalar.  Two patches are staged in LDS with aligned 4-byte loads:
+// 31 x 31 of the unblurred level (intensity centroid over the radius-15 disc) and
+// 37 x 37 of the blurred level (256 rotated rBRIEF comparisons, 4 per lane, assembled
+// by ballot; the rotated pattern reaches at most 18 pixels).  Keypoints lie >= 31
+// pixels from the level border, so both patches are inside the level.
 // ---------------------------------------------------------------------------
 constexpr int kURad = 15, kURows = 31, kUPitch = 36;   // 31 columns + up to 3 alignment bytes
 constexpr int kBRad = 18, kBRows = 37, kBPitch = 40;   // 37 columns + up to 3 alignment bytes
 constexpr int kWaveLds = kURows * kUPitch + kBRows * kBPitch;  // 2596
 
-__constant__ __align__(16) int8_t c_pattern[256 * 4] = {
+// rBRIEF sampling pattern as floats: x0, y0, x1, y1 of pair p at [4 * p].
+__constant__ __align__(16) float c_pattern[256 * 4] = {
 #include "orb_pattern_31.inc"
 };
 
 // Half-width of row |v| of the radius-15 disc, 4 bits per row:
-// 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3 for |v| = 0 .. 15.
+// 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3 for |v| = 0 .. 15.  The disc is
+// symmetric, so the same table gives the half-height of column |u|.
 __device__ __forceinline__ int disc_half_width(int av) {
     const unsigned long long packed = 0x3689ABCDDEEEFFFFull;
     return (int)((packed >> (4 * av)) & 15u);
@@ -663,20 +665,31 @@ __device__ __forceinline__ int disc_half_width(int av) {
 
 // Copies rows [y - R, y + R] x columns [x - R, x + R] of img into LDS.  Returns
 // the column shift: patch column c of row r is at dst[r * PITCH + shift + c].
+// A lane keeps one (row, dword) position of a block of 64 / DW rows and walks
+// down the patch block by block: the loads of all blocks are issued together.
 template <int R, int PITCH>
 __device__ __forceinline__ int stage_patch(const uint8_t* img, int pitch, bool aligned, int x, int y,
                                            uint8_t* dst, int lane) {
     constexpr int ROWS = 2 * R + 1;
     const uint8_t* p0 = img + (size_t)(y - R) * pitch + (x - R);
     if (aligned) {
+        constexpr int DW = PITCH / 4, RPI = 64 / DW, ITERS = (ROWS + RPI - 1) / RPI;
         const int shift = (int)(reinterpret_cast<uintptr_t>(p0) & 3);
-        constexpr int DW = PITCH / 4;
         const uint8_t* base = p0 - shift;
-        for (int k = lane; k < ROWS * DW; k += 64) {
-            const int r = k / DW, c = k - r * DW;
-            *reinterpret_cast<uint32_t*>(dst + r * PITCH + 4 * c) =
-                *reinterpret_cast<const uint32_t*>(base + (size_t)r * pitch + 4 * c);
+        const int lr = lane / DW, lc = lane - lr * DW;
+        const unsigned voff = (unsigned)(lr * pitch + 4 * lc);
+        uint8_t* d = dst + lr * PITCH + 4 * lc;
+        uint32_t v[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            v[it] = 0;
+            if (lr < RPI && lr + it * RPI < ROWS)
+                v[it] = *reinterpret_cast<const uint32_t*>(base + (size_t)(it * RPI) * pitch + voff);
         }
+#pragma unroll
+        for (int it = 0; it < ITERS; it++)
+            if (lr < RPI && lr + it * RPI < ROWS)
+                *reinterpret_cast<uint32_t*>(d + it * RPI * PITCH) = v[it];
         return shift;
     }
     for (int k = lane; k < ROWS * ROWS; k += 64) {
@@ -686,23 +699,32 @@ __device__ __forceinline__ int stage_patch(const uint8_t* img, int pitch, bool a
     return 0;
 }
 
-__global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
-    __shared__ __align__(16) uint8_t s_all[4 * kWaveLds];
+// Sum over the 64 lanes, returned in a scalar register: butterfly inside each row of
+// 16 lanes with DPP, then the four row sums are read out.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);  // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+__global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
+    __shared__ __align__(16) uint8_t s_all[kWaveLds + 64];
     // 1-D grid, frame index fastest, so the workgroups beyond the last keypoint of
     // every frame (they exit at once) sit at the end of the grid.
     const int b = blockIdx.x % a.batch;
-    const int blk = blockIdx.x / a.batch;
+    const int i = blockIdx.x / a.batch;
     const int n = min(a.sel[b].total, a.capacity);
-    if (blk * 4 >= n) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blk * 4 + wave;
-    if (i >= n) return;               // waves are independent: no workgroup barrier below
-    uint8_t* s_u = s_all + wave * kWaveLds;
-    uint8_t* s_b = s_u + kURows * kUPitch;
+    if (i >= n) return;
+    const int lane = threadIdx.x;
+    uint8_t* s_u = s_all;
+    uint8_t* s_b = s_all + kURows * kUPitch;
     // the lane's four pattern rows (pair p = 64*k + lane), fetched ahead of everything else
-    uint32_t pat[4];
+    float4 pat[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const uint32_t*>(c_pattern)[64 * k + lane];
+    for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const float4*>(c_pattern)[64 * k + lane];
 
     slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity + i;
     const uint32_t xy = a.kpxy[(size_t)b * a.capacity + i];
@@ -729,28 +751,30 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- intensity centroid: two disc rows per step (lanes 0-30 / 32-62) ----
-    const uint8_t* ctr = s_u + kURad * kUPitch + su + kURad;
-    int m10 = 0, m01 = 0;
+    // ---- intensity centroid ----
+    // Lanes 0-30 own the columns u = -15..15 for the rows v = -15..0, lanes 32-62 the
+    // same columns for v = 1..15.  A lane adds up its column (rows outside the disc
+    // masked off) and the row-weighted sum; the column weight is applied once.
+    int m10, m01;
     {
-        const int half = lane >> 5, u = (lane & 31) - 15;
-#pragma unroll 1
-        for (int vv = 0; vv < 16; vv++) {
-            // half 0: v = -15 + vv (v in [-15, 0]); half 1: v = 1 + vv (v in [1, 16], 16 unused)
-            const int v = half ? (1 + vv) : (-15 + vv);
-            const int av = v < 0 ? -v : v;
-            const int hw = disc_half_width(av & 15);
-            if (av <= 15 && (lane & 31) < 31 && u >= -hw && u <= hw) {
-                const int val = ctr[v * kUPitch + u];
-                m10 += u * val;
-                m01 += v * val;
-            }
-        }
-    }
+        const int col = lane & 31, half = lane >> 5;
+        const int u = col - 15;
+        const int vlim = col < 31 ? disc_half_width(u < 0 ? -u : u) : -1;  // |v| <= vlim is inside
+        const int vbase = half ? 1 : -15;                                  // v = vbase + vv, vv = 0..15
+        const int lo = half ? 0 : 15 - vlim, hi = half ? vlim - 1 : 15;    // vv range inside the disc
+        const unsigned rows = hi >= lo ? (2u << hi) - (1u << lo) : 0u;
+        // column 31 (u = 16) and row v = 16 are masked off; their reads stay inside s_all
+        const uint8_t* colp = s_u + (kURad + vbase) * kUPitch + su + kURad + u;
+        int colsum = 0, vsum = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o, 64);
-        m01 += __shfl_xor(m01, o, 64);
+        for (int vv = 0; vv < 16; vv++) {
+            int val = colp[vv * kUPitch];
+            val &= ((int)(rows << (31 - vv))) >> 31;
+            colsum += val;
+            vsum += vv * val;
+        }
+        m10 = wave_sum_i32(u * colsum);
+        m01 = wave_sum_i32(vbase * colsum + vsum);
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
@@ -759,21 +783,21 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
     float ca, sb_;
     sincos_f32(rad, &ca, &sb_);
     const uint8_t* bc = s_b + kBRad * kBPitch + sb + kBRad;
-    unsigned long long* out = reinterpret_cast<unsigned long long*>(a.desc + ((size_t)b * a.capacity + i) * 32);
+    unsigned long long bits[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const float px0 = (float)(int8_t)(pat[k] & 255u), py0 = (float)(int8_t)((pat[k] >> 8) & 255u);
-        const float px1 = (float)(int8_t)((pat[k] >> 16) & 255u), py1 = (float)(int8_t)(pat[k] >> 24);
-        const int ix0 = SA_RINT_I(SA_FSUB(SA_FMUL(px0, ca), SA_FMUL(py0, sb_)));
-        const int iy0 = SA_RINT_I(SA_FADD(SA_FMUL(px0, sb_), SA_FMUL(py0, ca)));
-        const int ix1 = SA_RINT_I(SA_FSUB(SA_FMUL(px1, ca), SA_FMUL(py1, sb_)));
-        const int iy1 = SA_RINT_I(SA_FADD(SA_FMUL(px1, sb_), SA_FMUL(py1, ca)));
+        const int ix0 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].x, ca), SA_FMUL(pat[k].y, sb_)));
+        const int iy0 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].x, sb_), SA_FMUL(pat[k].y, ca)));
+        const int ix1 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].z, ca), SA_FMUL(pat[k].w, sb_)));
+        const int iy1 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].z, sb_), SA_FMUL(pat[k].w, ca)));
         const int t0 = bc[iy0 * kBPitch + ix0];
         const int t1 = bc[iy1 * kBPitch + ix1];
-        const unsigned long long bits = __ballot(t0 < t1);
-        if (lane == 0) out[k] = bits;
+        bits[k] = __ballot(t0 < t1);
     }
     if (lane == 0) {
+        uint4* out = reinterpret_cast<uint4*>(a.desc + ((size_t)b * a.capacity + i) * 32);
+        out[0] = make_uint4((unsigned)bits[0], (unsigned)(bits[0] >> 32), (unsigned)bits[1], (unsigned)(bits[1] >> 32));
+        out[1] = make_uint4((unsigned)bits[2], (unsigned)(bits[2] >> 32), (unsigned)bits[3], (unsigned)(bits[3] >> 32));
         kp->angle = angle;
         kp->x = SA_FMUL((float)x, L.scale);
         kp->y = SA_FMUL((float)y, L.scale);
@@ -810,8 +834,10 @@ int launch_select_compact(const SelectCompactArgs& a, int batch, hipStream_t st)
 int launch_describe(const DescribeArgs& a, int batch, hipStream_t st) {
     DescribeArgs d = a;
     d.batch = batch;
-    dim3 grid((unsigned)(div_up(a.capacity, 4) * batch));
-    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), 0, st, d);
+    const long long blocks = (long long)a.capacity * batch;
+    if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "describe: capacity x batch too large for one launch");
+    dim3 grid((unsigned)blocks);
+    hipLaunchKernelGGL(describe_kernel, grid, dim3(64), 0, st, d);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }

@@ -32,18 +32,21 @@ def chunk_rows(per, chunks, c):
 class PairGather:
     """Per-rank result buffer [per, n_per] int32 plus the chunked gather to rank 0."""
 
-    def __init__(self, torch, dist, n_pairs, n_per, world, rank, device, chunks):
+    def __init__(self, torch, dist, n_pairs, n_per, world, rank, device, chunks, collective=None):
+        """collective: run the gather even for world == 1 (a one-rank process group, to
+        exercise the exchange on a single GPU); default: only when world > 1."""
         self.torch, self.dist = torch, dist
         self.world, self.rank, self.chunks = world, rank, max(1, chunks)
+        self.collective = (world > 1) if collective is None else bool(collective)
         self.lo, self.hi, self.per = shard(n_pairs, world, rank)
         self.mine = self.hi - self.lo
         self.n_pairs, self.n_per = n_pairs, n_per
         self.res = torch.full((max(self.per, 1), n_per), -1, dtype=torch.int32, device=device)
         self.gathered = None
-        if world > 1 and rank == 0:
+        if self.collective and rank == 0:
             self.gathered = torch.empty((world, max(self.per, 1), n_per), dtype=torch.int32, device=device)
         self.on_gpu = (getattr(device, "type", str(device)) == "cuda")
-        self.comm = torch.cuda.Stream(device=device) if (self.on_gpu and world > 1) else None
+        self.comm = torch.cuda.Stream(device=device) if (self.on_gpu and self.collective) else None
 
     def run(self, compute, limit=None):
         """compute(a, b) fills rows [a, b) of self.res (local pair indices lo+a .. lo+b).
@@ -59,7 +62,7 @@ class PairGather:
                 b = min(b, a + limit)
             if b > a:
                 compute(a, b)
-            if self.world > 1 and limit is None and cb > ca:
+            if self.collective and limit is None and cb > ca:
                 src = self.res[ca:cb]
                 outs = [self.gathered[r, ca:cb] for r in range(self.world)] if self.rank == 0 else None
                 if self.comm is not None:
@@ -77,7 +80,7 @@ class PairGather:
 
     def result(self):
         """On rank 0: [n_pairs, n_per] rows in pair-list order (a view when world == 1)."""
-        if self.world == 1:
+        if not self.collective:
             return self.res[:self.n_pairs]
         if self.rank != 0:
             return None
