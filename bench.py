@@ -80,14 +80,13 @@ def main():
             raise SystemExit("--gpus %d needs a torch.distributed.run launch with that many ranks" % args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # under torch.distributed.run the process group is used even with one rank, so that a
-    # one-GPU launch exercises the same RCCL calls (barrier, all_reduce, gather) as N ranks
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    dist_up = [False]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         torch.cuda.synchronize()
-        if dist_up[0]:
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -113,6 +112,7 @@ def main():
     kp_p, desc_p, cnt_p = d_kp.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr()
 
     def step():
+        nonlocal stream
         ex.extract_batch_async(d_img, B, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
         m.frame_match_batch_async(B, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
                                   cnt_p + 4, d_out, d_nout, max_dist=300.0, area=-1.0, max_level=-1,
@@ -122,49 +122,9 @@ def main():
         d_desc[:CAP * 32].copy_(d_desc[B * CAP * 32:(B + 1) * CAP * 32], non_blocking=True)
         d_cnt[:1].copy_(d_cnt[B:B + 1], non_blocking=True)
 
-    def one_frame():
-        ex.extract_batch_async(d_img, 1, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
-        m.frame_match_batch_async(1, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
-                                  cnt_p + 4, d_out, d_nout, 300.0, -1.0, -1, stream)
-
-    def capture(fn):
-        """fn's launches as a HIP graph (None if capture is not possible)."""
-        nonlocal stream
-        try:
-            torch.cuda.synchronize()
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                stream = side.cuda_stream
-                fn()                        # warm-up on the capture stream
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                stream = side.cuda_stream
-                fn()
-            return g
-        except Exception as e:  # capture unsupported: the eager timing is reported
-            sys.stderr.write("graph capture failed (%s); timing eager launches\n" % e)
-            return None
-        finally:
-            stream = torch.cuda.current_stream().cuda_stream
-
     step()  # fills slot 0
     for _ in range(args.warmup):
         step()
-    for _ in range(3):
-        one_frame()
-    # Both graphs are captured before the process group exists: RCCL's watchdog thread
-    # polls events, which is not allowed while another thread captures in global mode.
-    graph = None if args.no_graph else capture(step)
-    graph1 = None if (args.no_graph or rank != 0) else capture(one_frame)
-    torch.cuda.synchronize()
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-        dist_up[0] = True
-
     # ---- eager pass with per-stage HIP events (stage times, roofline of the dominant kernel) ----
     capi.prof_enable(args.steps * 12 + 16)
     barrier()
@@ -175,10 +135,32 @@ def main():
     dt_eager = time.perf_counter() - t0
     stages = capi.prof_collect()
     capi.prof_enable(0)
-    # ---- timed region: the same step replayed from its HIP graph ----
+    # ---- timed region: the same step captured once into a HIP graph and replayed ----
+    graph = None
+    # With a process group up (N > 1) the launches stay eager: RCCL's watchdog thread polls
+    # events, which a stream capture in global mode on another thread does not tolerate.
+    if not args.no_graph and world == 1:
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                stream = side.cuda_stream
+                step()                      # warm-up on the capture stream
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                stream = side.cuda_stream
+                step()
+            stream = torch.cuda.current_stream().cuda_stream
+            for _ in range(args.warmup):
+                graph.replay()
+        except Exception as e:  # capture unsupported: report the eager timing
+            sys.stderr.write("graph capture failed (%s); timing eager launches\n" % e)
+            graph = None
+            stream = torch.cuda.current_stream().cuda_stream
     if graph is not None:
-        for _ in range(args.warmup):
-            graph.replay()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -187,7 +169,7 @@ def main():
         dt = time.perf_counter() - t0
     else:
         dt = dt_eager
-    if dist_up[0]:
+    if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -199,24 +181,44 @@ def main():
     lat_ms = None
     lat_graph_ms = None
     if rank == 0:
-        reps = 50
         for _ in range(3):
-            one_frame()
+            ex.extract_batch_async(d_img, 1, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
+            m.frame_match_batch_async(1, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
+                                      cnt_p + 4, d_out, d_nout, 300.0, -1.0, -1, stream)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        reps = 50
         for _ in range(reps):
-            one_frame()
+            ex.extract_batch_async(d_img, 1, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
+            m.frame_match_batch_async(1, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
+                                      cnt_p + 4, d_out, d_nout, 300.0, -1.0, -1, stream)
             torch.cuda.synchronize()
         lat_ms = (time.perf_counter() - t1) / reps * 1e3
-        if graph1 is not None:
-            for _ in range(3):
-                graph1.replay()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                graph1.replay()
+        lat_graph_ms = None
+        if graph is not None:
+            try:
+                def one():
+                    ex.extract_batch_async(d_img, 1, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
+                    m.frame_match_batch_async(1, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
+                                              cnt_p + 4, d_out, d_nout, 300.0, -1.0, -1, stream)
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream())
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, stream=side):
+                    stream = side.cuda_stream
+                    one()
+                stream = torch.cuda.current_stream().cuda_stream
+                for _ in range(3):
+                    g1.replay()
                 torch.cuda.synchronize()
-            lat_graph_ms = (time.perf_counter() - t1) / reps * 1e3
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    g1.replay()
+                    torch.cuda.synchronize()
+                lat_graph_ms = (time.perf_counter() - t1) / reps * 1e3
+            except Exception as e:
+                sys.stderr.write("batch-1 graph capture failed: %s\n" % e)
+                stream = torch.cuda.current_stream().cuda_stream
 
     # ---- roofline of the dominant kernel (algorithmic bytes per launch / event time) ----
     px = pyramid_pixels(ws, hs)
@@ -264,7 +266,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(args, synth, seq)
 
-    if dist_up[0]:
+    if world > 1:
         dist.destroy_process_group()
     if rank == 0:
         line = {
@@ -308,8 +310,7 @@ def run_pairs(args, torch, dist, capi, synth, m, dev, rank, world, barrier):
     d_desc = torch.from_numpy(desc).to(dev)
     pairs = pairs_mod.all_pairs(n_kf)
     n_pairs = len(pairs)
-    pg = pairs_mod.PairGather(torch, dist, n_pairs, n_per, world, rank, dev, args.pair_chunks,
-                              collective=dist.is_initialized())
+    pg = pairs_mod.PairGather(torch, dist, n_pairs, n_per, world, rank, dev, args.pair_chunks)
     d_pairs = torch.from_numpy(np.ascontiguousarray(pairs[pg.lo:max(pg.hi, pg.lo + 1)])).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -323,7 +324,7 @@ def run_pairs(args, torch, dist, capi, synth, m, dev, rank, world, barrier):
     pg.run(compute)
     barrier()
     dt = time.perf_counter() - t0
-    if dist.is_initialized():
+    if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -484,4 +485,15 @@ def cpu_baseline(args, synth, seq):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        # Leave without unwinding GPU objects: destructors that run after a failed HIP call
+        # can throw again and turn an ordinary error into an abort with work still queued.
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(1)

@@ -371,6 +371,11 @@ int orc_brief_descriptor(const uint8_t* blurred, int stride, int cx, int cy, flo
  * Canonical keypoint order: (octave, y, x) ascending. */
 int orc_detect_and_compute(const orc_params* p, const uint8_t* img, int w, int h, int stride,
                            orc_keypoint* kps, uint8_t* desc, int capacity, int* n) {
+    return orc_detect_and_compute_grid(p, 0, img, w, h, stride, kps, desc, capacity, n);
+}
+
+int orc_detect_and_compute_grid(const orc_params* p, int grid_cell, const uint8_t* img, int w, int h, int stride,
+                                orc_keypoint* kps, uint8_t* desc, int capacity, int* n) {
     int ws[ORC_MAX_LEVELS], hs[ORC_MAX_LEVELS], quotas[ORC_MAX_LEVELS];
     if (!n) return ORC_ERR_ARG;
     *n = 0;
@@ -413,6 +418,27 @@ int orc_detect_and_compute(const orc_params* p, const uint8_t* img, int w, int h
                     kept++;
                 }
             }
+        }
+        /* Option beyond the reference: one survivor per grid cell (cells anchored at the
+         * level origin): the highest score, the first in raster order among equals. */
+        if (grid_cell > 0 && kept > 0) {
+            const int cx_n = (lw + grid_cell - 1) / grid_cell, cy_n = (lh + grid_cell - 1) / grid_cell;
+            int* best = (int*)malloc(sizeof(int) * (size_t)cx_n * cy_n);
+            if (!best) { free(pyr); free(blur); free(cand); return ORC_ERR_NOMEM; }
+            for (int c = 0; c < cx_n * cy_n; c++) best[c] = -1;
+            for (int i = 0; i < kept; i++) {
+                const int c = (cand[3 * i + 1] / grid_cell) * cx_n + cand[3 * i] / grid_cell;
+                if (best[c] < 0 || cand[3 * i + 2] > cand[3 * best[c] + 2]) best[c] = i;
+            }
+            int k2 = 0;
+            for (int i = 0; i < kept; i++) {
+                const int c = (cand[3 * i + 1] / grid_cell) * cx_n + cand[3 * i] / grid_cell;
+                if (best[c] != i) continue;
+                cand[3 * k2] = cand[3 * i]; cand[3 * k2 + 1] = cand[3 * i + 1]; cand[3 * k2 + 2] = cand[3 * i + 2];
+                k2++;
+            }
+            kept = k2;
+            free(best);
         }
         /* KeyPointsFilter::retainBest(quota): cut at the quota-th best score, keep ties */
         int cut = 0;

@@ -108,6 +108,13 @@ int orc_brief_descriptor(const uint8_t* blurred, int stride, int cx, int cy, flo
 int orc_detect_and_compute(const orc_params* p, const uint8_t* img, int w, int h, int stride,
                            orc_keypoint* kps, uint8_t* desc, int capacity, int* n);
 
+/* The same with an option the reference does not have: grid_cell > 0 keeps, per level
+ * and after the border filter, only the best NMS survivor of every grid_cell x
+ * grid_cell cell (cells anchored at the level origin; highest score, first in raster
+ * order among equals) before the per-level quota is applied.  grid_cell 0 = off. */
+int orc_detect_and_compute_grid(const orc_params* p, int grid_cell, const uint8_t* img, int w, int h, int stride,
+                                orc_keypoint* kps, uint8_t* desc, int capacity, int* n);
+
 /* n_frames independent frames of one size (frame f at imgs + f*frame_pitch), each
  * processed by orc_detect_and_compute; frames run in parallel when the oracle is
  * built with OpenMP.  Outputs are [n_frames][capacity] records; counts[f] = n. */

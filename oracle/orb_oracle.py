@@ -172,7 +172,7 @@ def brief_descriptor(blurred, cx, cy, angle_deg):
     return d
 
 
-def detect_and_compute(p, img, capacity=None):
+def detect_and_compute(p, img, capacity=None, grid_cell=0):
     img = _img(img)
     h, w = img.shape
     if capacity is None:
@@ -181,8 +181,8 @@ def detect_and_compute(p, img, capacity=None):
         kps = np.zeros(capacity, KEYPOINT_DTYPE)
         desc = np.zeros((capacity, 32), np.uint8)
         n = C.c_int(0)
-        rc = lib().orc_detect_and_compute(C.byref(p), _p(img), w, h, img.strides[0],
-                                          _p(kps), _p(desc), capacity, C.byref(n))
+        rc = lib().orc_detect_and_compute_grid(C.byref(p), int(grid_cell), _p(img), w, h, img.strides[0],
+                                               _p(kps), _p(desc), capacity, C.byref(n))
         if rc == ERR_CAPACITY:
             capacity = n.value
             continue
