@@ -123,6 +123,14 @@ int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_t* d_images
                                  slam_amd_keypoint* d_kp, uint8_t* d_desc, int32_t* d_count,
                                  int capacity, void* stream);
 
+/* Grid distribution of keypoints -- not in the reference, whose cv::ORB keeps the
+ * per-level best-N by score only (src/frame/detector.cpp:11).  cell = 8, 16 or 32: per
+ * level and after the border filter, only the best NMS survivor of every cell x cell
+ * block of pixels (blocks anchored at the level origin; highest FAST score, first in
+ * raster order among equals) takes part in the per-level best-N selection.  cell = 0
+ * (the state after create) switches it off.  Applies to every later extract call. */
+int slam_amd_extractor_set_grid(slam_amd_extractor* ex, int cell);
+
 /* Copies one level of frame `frame` of the last batch to the host (widths[l]
  * columns, heights[l] rows, host_stride bytes per row): the unblurred pyramid
  * level, or the 7x7-blurred level the descriptors are sampled from.  For tests. */

@@ -132,6 +132,14 @@ public:
         }
     }
 
+    // Not in the reference: keep only the best corner of every cell x cell block of level
+    // pixels (cell = 8, 16 or 32; 0 = off, the default) before the per-level best-N cut.
+    void setGridCell(int cell) {
+        if (cell != 0 && cell != 8 && cell != 16 && cell != 32) throw Error(SLAM_AMD_ERR_ARG, "grid cell must be 0, 8, 16 or 32");
+        grid_cell_ = cell;
+        if (ex_) check(slam_amd_extractor_set_grid(ex_, cell));
+    }
+
     // reference: include/frame/detector.hpp:35-36
     int getLevels() const { return params_.nlevels; }
     double getScaleFactor() const { return static_cast<double>(params_.scale_factor); }
@@ -144,6 +152,7 @@ private:
         ex_ = nullptr;
         if (max_keypoints_ == 0) max_keypoints_ = std::max(4 * params_.nfeatures, 4096);
         check(slam_amd_extractor_create(&params_, w, h, 1, max_keypoints_, device_, &ex_));
+        check(slam_amd_extractor_set_grid(ex_, grid_cell_));
         width_ = w;
         height_ = h;
     }
@@ -151,6 +160,7 @@ private:
     int device_ = 0;
     slam_amd_extractor* ex_ = nullptr;
     int width_ = 0, height_ = 0, max_keypoints_ = 0;
+    int grid_cell_ = 0;
 };
 
 // ---------------------------------------------------------------------------

@@ -86,6 +86,7 @@ using namespace sa;
 // Extractor
 // =============================================================================
 struct slam_amd_extractor {
+    int grid_shift = 0;                // log2 of the grid-distribution cell, 0 = off (the reference)
     slam_amd_orb_params params;
     int width = 0, height = 0, max_batch = 0, max_keypoints = 0, device = 0;
     PyrGeom g;
@@ -343,6 +344,7 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     fa.pyr = ex->pyr.as<uint8_t>(); fa.smap = ex->smap.as<uint8_t>(); fa.blur = ex->blur.as<uint8_t>(); fa.hist = ex->hist.as<unsigned>();
     unsigned* rowfill = ex->hist.as<unsigned>() + (size_t)batch * g.nlevels * 256;
     fa.rowfill = rowfill; fa.rowlist = ex->rowlist.as<uint32_t>(); fa.g = g;
+    fa.grid_shift = ex->grid_shift; fa.tiles_all = 0; fa.tiles_per_xcd = 0;
     { ProfScope ps(kStageFast, st); if ((rc = launch_fast(fa, batch, st))) return rc; }
     SelectCompactArgs sc;
     sc.hist = ex->hist.as<unsigned>(); sc.rowfill = rowfill; sc.rowlist = ex->rowlist.as<uint32_t>();
@@ -413,6 +415,14 @@ static int debug_level(slam_amd_extractor* ex, int frame, int level, bool blurre
         SA_HIP(hipMemcpy2D(host_out, host_stride, base + (size_t)frame * ex->g.frame_bytes + L.off, L.pitch,
                            L.w, L.h, hipMemcpyDeviceToHost));
     }
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_extractor_set_grid(slam_amd_extractor* ex, int cell) {
+    if (!ex) SA_FAIL(SLAM_AMD_ERR_ARG, "extractor is null");
+    if (cell != 0 && cell != 8 && cell != 16 && cell != 32)
+        SA_FAIL(SLAM_AMD_ERR_ARG, "grid cell must be 0 (off), 8, 16 or 32");
+    ex->grid_shift = cell == 8 ? 3 : cell == 16 ? 4 : cell == 32 ? 5 : 0;
     return SLAM_AMD_OK;
 }
 

@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     __shared__ __align__(16) uint8_t s_scratch[2 * kListBytes];
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_n[2];
+    __shared__ unsigned s_cellbest[(kFastTileW / 8) * (kFastTileH / 8)];   // grid cells of >= 8 x 8 pixels
     uint16_t* s_list1 = reinterpret_cast<uint16_t*>(s_scratch);
     uint16_t* s_list2 = reinterpret_cast<uint16_t*>(s_scratch + kListBytes);
     unsigned* s_row = reinterpret_cast<unsigned*>(s_scratch);  // [38][32] packed u16 pairs
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     const int tid = threadIdx.x;
     s_hist[tid] = 0;
     if (tid < 2) s_n[tid] = 0;
+    if (tid < (kFastTileW / 8) * (kFastTileH / 8)) s_cellbest[tid] = 0;
     // Thread (column group cg, row rr) of an 18 x 14 arrangement: one dword column
     // of the staged tile, rows rr, rr + 14, rr + 28.  252 of the 256 threads take part.
     const int rr = tid / 18, cg = tid - rr * 18;
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     const bool level_ok = (w > 2 * edge) && (h > 2 * edge);
     {
         const int tx = tid & 15, tr = tid >> 4;
+        uint32_t keep[2] = {0u, 0u};   // NMS survivors of this thread's 4 pixels in rows tr and tr + 16
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
             const int ly = tr + 16 * rr;
@@ -387,14 +390,55 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
                     if (s == 0 || gx < edge || gx >= w - edge) continue;
                     const uint8_t* q = q0 + j;
                     if (s > q[-1] && s > q[1] && s > q[-kScPitch - 1] && s > q[-kScPitch] &&
-                        s > q[-kScPitch + 1] && s > q[kScPitch - 1] && s > q[kScPitch] && s > q[kScPitch + 1]) {
+                        s > q[-kScPitch + 1] && s > q[kScPitch - 1] && s > q[kScPitch] && s > q[kScPitch + 1])
                         packed |= (uint32_t)s << (8 * j);
-                        atomicAdd(&s_hist[s], 1u);
-                        const size_t row = (size_t)b * a.g.total_rows + L.row_base + gy;
-                        const unsigned slot = atomicAdd(&a.rowfill[row], 1u);
-                        if (slot < (unsigned)a.g.rowcap)
-                            a.rowlist[row * kRowListCap + slot] = (uint32_t)gx | ((uint32_t)s << 16);
+                }
+            }
+            keep[rr] = packed;
+        }
+        // Optional grid distribution (not in the reference): of the survivors of one
+        // cell of grid_cell x grid_cell pixels only the best stays -- highest score,
+        // first in raster order among equals.  Cells are anchored at the level origin
+        // and divide the tile, so the contest is local to the workgroup.
+        if (a.grid_shift) {
+            const int sh = a.grid_shift;
+            auto contest = [&](bool write) {
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const int ly = tr + 16 * rr;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const unsigned s = (keep[rr] >> (8 * j)) & 255u;
+                        if (s == 0) continue;
+                        const int lx = 4 * tx + j;
+                        const int cell = (ly >> sh) * (kFastTileW >> sh) + (lx >> sh);
+                        const unsigned key = (s << 16) | (0xffffu - (unsigned)(ly * kFastTileW + lx));
+                        if (write) atomicMax(&s_cellbest[cell], key);
+                        else if (s_cellbest[cell] != key) keep[rr] &= ~(255u << (8 * j));
                     }
+                }
+            };
+            contest(true);
+            __syncthreads();
+            contest(false);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int ly = tr + 16 * rr;
+            const int gy = y0 + ly;
+            if (gy >= h) continue;
+            const uint32_t packed = keep[rr];
+            if (packed) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned s = (packed >> (8 * j)) & 255u;
+                    if (s == 0) continue;
+                    const int gx = x0 + 4 * tx + j;
+                    atomicAdd(&s_hist[s], 1u);
+                    const size_t row = (size_t)b * a.g.total_rows + L.row_base + gy;
+                    const unsigned slot = atomicAdd(&a.rowfill[row], 1u);
+                    if (slot < (unsigned)a.g.rowcap)
+                        a.rowlist[row * kRowListCap + slot] = (uint32_t)gx | ((uint32_t)s << 16);
                 }
             }
             *reinterpret_cast<uint32_t*>(smap + (size_t)gy * L.pitch + x0 + 4 * tx) = packed;

@@ -31,6 +31,7 @@ struct FastArgs {
     unsigned* hist;       // [batch][nlevels][256]
     unsigned* rowfill;    // [batch][total_rows] survivors appended to each row's list
     uint32_t* rowlist;    // [batch][total_rows][kRowListCap]
+    int grid_shift;       // 0: off; 3, 4, 5: keep the best survivor of every 8, 16, 32 pixel cell
     int tiles_all;        // total_tiles * batch (set by the launcher)
     int tiles_per_xcd;    // ceil(tiles_all / 8)
     PyrGeom g;

@@ -528,3 +528,32 @@ def test_ratio_and_rotation_options_known_answers(oracle):
     kp["angle"][11] = 359.0
     got = oracle.match_gated_ex(np.zeros((12, 32), np.uint8), kp, td, tk, 300.0, -1.0, -1, 0.0, 30)
     assert len(got) == 12
+
+
+def test_grid_distribution_option_known_properties(oracle):
+    """Grid option (not in the reference): one keypoint per cell and level, the cell's best."""
+    from slam_amd import synth
+    img = synth.scene(320, 240, seed=5)
+    p = oracle.params(nfeatures=100000)            # quota never cuts: isolates the grid rule
+    base, _ = oracle.detect_and_compute(p, img)
+    for cell in (8, 16, 32):
+        kp, desc = oracle.detect_and_compute(p, img, grid_cell=cell)
+        assert 0 < len(kp) < len(base)
+        for lvl in range(8):
+            sf = np.float32(oracle.level_scale(p, lvl))
+            a = base[base["octave"] == lvl]
+            g = kp[kp["octave"] == lvl]
+            ax = np.rint(a["x"] / sf).astype(int); ay = np.rint(a["y"] / sf).astype(int)
+            gx = np.rint(g["x"] / sf).astype(int); gy = np.rint(g["y"] / sf).astype(int)
+            cells_a = (ay // cell) * 10000 + ax // cell
+            cells_g = (gy // cell) * 10000 + gx // cell
+            assert len(np.unique(cells_g)) == len(cells_g)                 # one per cell
+            assert set(cells_g.tolist()) == set(cells_a.tolist())          # every occupied cell keeps one
+            for c, r, x, y in zip(cells_g, g["response"], gx, gy):
+                inside = cells_a == c
+                assert r == a["response"][inside].max()
+                first = np.flatnonzero(inside & (a["response"] == r))[0]   # base is in raster order per level
+                assert (ax[first], ay[first]) == (x, y)
+    # grid off is the plain path
+    k0, d0 = oracle.detect_and_compute(p, img, grid_cell=0)
+    assert np.array_equal(k0, base)
