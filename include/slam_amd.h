@@ -259,6 +259,21 @@ int slam_amd_duplicate_pairs(slam_amd_matcher* m,
                              const uint8_t* desc2, const float* pos2, int n2,
                              int desc_dist, double point_dist, uint8_t* flag);
 
+/* Host, blocking.  isOutlier of src/map/mappoint.cpp:54-81 (with projectionError,
+ * :83-101) for n triangulated points at once, as Mapper calls it per point at
+ * src/tracking/mapper.cpp:48 and :121.  Point i belongs to matches[i] (queryIdx into
+ * kp_q, trainIdx into kp_t; undistorted keypoints of the two keyframes).  flags[i] = 1
+ * when the point is NaN, the cosine of its parallax between the two camera centres is
+ * outside [0, 0.999f], it lies within 1e-6 of a centre, or it reprojects more than one
+ * pixel from its keypoint in either keyframe.  center_*: 3 floats (-R^T t); Rt_*: pose
+ * as row-major 3x4 doubles; K4_*: fx fy cx cy; dist5_*: k1 k2 p1 p2 k3 or NULL. */
+int slam_amd_outlier_flags(slam_amd_matcher* m, const float* xyz, const slam_amd_dmatch* matches, int n,
+                           const slam_amd_keypoint* kp_q, int nq, const slam_amd_keypoint* kp_t, int nt,
+                           const float* center_q, const float* center_t,
+                           const double* Rt_q, const double* K4_q, const double* dist5_q,
+                           const double* Rt_t, const double* K4_t, const double* dist5_t,
+                           uint8_t* flags);
+
 /* ---- per-stage timing (process-wide, off by default) -------------------------
  * With max_marks > 0 every kernel stage launched through this library is
  * bracketed by HIP events on its own stream (up to max_marks stages recorded);

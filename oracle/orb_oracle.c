@@ -739,6 +739,49 @@ int orc_project_points(const double* Rt, const double* K4, const double* dist5,
     return ORC_OK;
 }
 
+/* projectionError (src/map/mappoint.cpp:83-101): distance between the keypoint and the
+ * projection of the point, cv::norm(Point2f) accumulating in double. */
+static double projection_error(const double* Rt, const double* K4, const double* dist5,
+                               const float* xyz, float tx, float ty) {
+    float uv[2];
+    orc_project_points(Rt, K4, dist5, xyz, 1, uv);
+    const float dx = tx - uv[0], dy = ty - uv[1];
+    return sqrt((double)dx * dx + (double)dy * dy);
+}
+
+/* isOutlier (src/map/mappoint.cpp:54-81) for n triangulated points: point i belongs to
+ * matches[i] (queryIdx into kp_q, trainIdx into kp_t).  Differences are float (cv::Mat
+ * CV_32F subtraction), dot products and norms of the 3-vectors accumulate in double. */
+int orc_outlier_flags(const float* xyz, const orc_dmatch* matches, int n,
+                      const orc_keypoint* kp_q, int nq, const orc_keypoint* kp_t, int nt,
+                      const float* center_q, const float* center_t,
+                      const double* Rt_q, const double* K4_q, const double* dist5_q,
+                      const double* Rt_t, const double* K4_t, const double* dist5_t,
+                      uint8_t* flags) {
+    if (!xyz || !matches || !kp_q || !kp_t || !center_q || !center_t || !flags || n < 0) return ORC_ERR_ARG;
+    for (int i = 0; i < n; i++) {
+        const float* P = xyz + 3 * i;
+        const int qi = matches[i].queryIdx, ti = matches[i].trainIdx;
+        if (qi < 0 || qi >= nq || ti < 0 || ti >= nt) return ORC_ERR_ARG;
+        flags[i] = 1;
+        if (isnan(P[0])) continue;
+        float a[3], b[3];
+        for (int k = 0; k < 3; k++) { a[k] = P[k] - center_q[k]; b[k] = P[k] - center_t[k]; }
+        double dot = 0, na = 0, nb = 0;
+        for (int k = 0; k < 3; k++) {
+            dot += (double)a[k] * b[k]; na += (double)a[k] * a[k]; nb += (double)b[k] * b[k];
+        }
+        na = sqrt(na); nb = sqrt(nb);
+        const double par = dot / (na * nb);
+        if (par < 0.0f || par > 0.999f) continue;
+        if (fabs(na) < 1E-6 || fabs(nb) < 1E-6) continue;
+        if (projection_error(Rt_q, K4_q, dist5_q, P, kp_q[qi].x, kp_q[qi].y) > 1) continue;
+        if (projection_error(Rt_t, K4_t, dist5_t, P, kp_t[ti].x, kp_t[ti].y) > 1) continue;
+        flags[i] = 0;
+    }
+    return ORC_OK;
+}
+
 int orc_duplicate_pairs(const uint8_t* d1, const float* p1, int n1,
                         const uint8_t* d2, const float* p2, int n2,
                         int desc_dist, double point_dist, uint8_t* flag) {

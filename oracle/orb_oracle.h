@@ -176,6 +176,18 @@ int orc_frame_match(const uint8_t* d1, const orc_keypoint* kp1, int n1,
 int orc_project_points(const double* Rt, const double* K4, const double* dist5,
                        const float* xyz, int n, float* uv);
 
+/* isOutlier over n triangulated points (src/map/mappoint.cpp:54-101): flags[i] = 1 when
+ * the point is NaN, its parallax cosine is outside [0, 0.999f], it lies within 1e-6 of
+ * a camera centre, or it reprojects more than 1 pixel from matches[i]'s keypoint in
+ * either keyframe.  Poses as row-major 3x4 [R|t] (the reference passes R through
+ * cv::Rodrigues and back, which this restatement does not repeat). */
+int orc_outlier_flags(const float* xyz, const orc_dmatch* matches, int n,
+                      const orc_keypoint* kp_q, int nq, const orc_keypoint* kp_t, int nt,
+                      const float* center_q, const float* center_t,
+                      const double* Rt_q, const double* K4_q, const double* dist5_q,
+                      const double* Rt_t, const double* K4_t, const double* dist5_t,
+                      uint8_t* flags);
+
 /* Mapper::_isDuplicate over all pairs (src/tracking/mapper.cpp:328-346):
  * flag[i*n2+j] = hamming(d1[i], d2[j]) <= desc_dist && |p1[i]-p2[j]| < point_dist. */
 int orc_duplicate_pairs(const uint8_t* d1, const float* p1, int n1,

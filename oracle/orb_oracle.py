@@ -280,6 +280,22 @@ def project_points(Rt, K4, dist5, xyz):
     return uv
 
 
+def outlier_flags(xyz, matches, kp_q, kp_t, center_q, center_t, Rt_q, K4_q, dist5_q, Rt_t, K4_t, dist5_t):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    matches = np.ascontiguousarray(matches, DMATCH_DTYPE)
+    kp_q = np.ascontiguousarray(kp_q, KEYPOINT_DTYPE); kp_t = np.ascontiguousarray(kp_t, KEYPOINT_DTYPE)
+    cq = np.ascontiguousarray(center_q, np.float32).reshape(3); ct = np.ascontiguousarray(center_t, np.float32).reshape(3)
+    f64 = lambda v, n: None if v is None else np.ascontiguousarray(v, np.float64).reshape(n)
+    a = [f64(Rt_q, 12), f64(K4_q, 4), f64(dist5_q, 5), f64(Rt_t, 12), f64(K4_t, 4), f64(dist5_t, 5)]
+    flags = np.zeros(len(xyz), np.uint8)
+    fn = lib().orc_outlier_flags
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 9
+    rc = fn(_p(xyz), _p(matches), len(xyz), _p(kp_q), len(kp_q), _p(kp_t), len(kp_t), _p(cq), _p(ct),
+            *[None if v is None else _p(v) for v in a], _p(flags))
+    if rc: raise ValueError(rc)
+    return flags
+
+
 def duplicate_pairs(d1, p1, d2, p2, desc_dist=100, point_dist=1e-2):
     d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
     d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)

@@ -34,6 +34,7 @@ EXPORTS = [
     "slam_amd_frame_match", "slam_amd_frame_match_async", "slam_amd_frame_match_batch_async",
     "slam_amd_match_pairs_async",
     "slam_amd_project_points", "slam_amd_project_points_async", "slam_amd_duplicate_pairs",
+    "slam_amd_outlier_flags",
     "slam_amd_prof_enable", "slam_amd_prof_collect", "slam_amd_prof_stage_name",
     "slam_amd_sincos_f32", "slam_amd_fast_atan2", "slam_amd_linear_exact_coeffs",
 ]
@@ -316,6 +317,23 @@ class Matcher:
         check(lib().slam_amd_project_points(self._h, _ptr(Rt), _ptr(K4), _ptr(d5), _ptr(xyz), len(xyz),
                                              _ptr(uv)))
         return uv
+
+    def outlier_flags(self, xyz, matches, kp_q, kp_t, center_q, center_t, Rt_q, K4_q, dist5_q, Rt_t, K4_t, dist5_t):
+        """isOutlier of the reference for every (point, match): uint8 flags, 1 = outlier."""
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        matches = np.ascontiguousarray(matches, DMATCH_DTYPE)
+        kp_q = np.ascontiguousarray(kp_q, KEYPOINT_DTYPE); kp_t = np.ascontiguousarray(kp_t, KEYPOINT_DTYPE)
+        f32 = lambda v: np.ascontiguousarray(v, np.float32).reshape(3)
+        f64 = lambda v, n: None if v is None else np.ascontiguousarray(v, np.float64).reshape(n)
+        cq, ct = f32(center_q), f32(center_t)
+        a = [f64(Rt_q, 12), f64(K4_q, 4), f64(dist5_q, 5), f64(Rt_t, 12), f64(K4_t, 4), f64(dist5_t, 5)]
+        flags = np.zeros(len(xyz), np.uint8)
+        fn = lib().slam_amd_outlier_flags
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + \
+                      [C.c_void_p] * 9
+        check(fn(self._h, _ptr(xyz), _ptr(matches), len(xyz), _ptr(kp_q), len(kp_q), _ptr(kp_t), len(kp_t),
+                 _ptr(cq), _ptr(ct), *[None if v is None else _ptr(v) for v in a], _ptr(flags)))
+        return flags
 
     def duplicate_pairs(self, d1, p1, d2, p2, desc_dist=100, point_dist=1e-2):
         d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)

@@ -790,6 +790,45 @@ extern "C" int slam_amd_duplicate_pairs(slam_amd_matcher* m,
     return SLAM_AMD_OK;
 }
 
+extern "C" int slam_amd_outlier_flags(slam_amd_matcher* m, const float* xyz, const slam_amd_dmatch* matches, int n,
+                                      const slam_amd_keypoint* kp_q, int nq, const slam_amd_keypoint* kp_t, int nt,
+                                      const float* center_q, const float* center_t,
+                                      const double* Rt_q, const double* K4_q, const double* dist5_q,
+                                      const double* Rt_t, const double* K4_t, const double* dist5_t,
+                                      uint8_t* flags) {
+    if (!m) SA_FAIL(SLAM_AMD_ERR_ARG, "matcher is null");
+    if (n < 0 || nq < 0 || nt < 0) SA_FAIL(SLAM_AMD_ERR_ARG, "negative size");
+    if (n == 0) return SLAM_AMD_OK;
+    if (!xyz || !matches || !kp_q || !kp_t || !center_q || !center_t || !Rt_q || !K4_q || !Rt_t || !K4_t || !flags)
+        SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    for (int i = 0; i < n; i++)
+        if (matches[i].queryIdx < 0 || matches[i].queryIdx >= nq || matches[i].trainIdx < 0 || matches[i].trainIdx >= nt)
+            SA_FAIL(SLAM_AMD_ERR_ARG, "match index out of range");
+    SA_HIP(hipSetDevice(m->device));
+    hipStream_t st = m->stream;
+    int rc;
+    if ((rc = upload(m->h_xy, xyz, (size_t)n * 3 * sizeof(float), st))) return rc;
+    if ((rc = upload(m->h_out, matches, (size_t)n * sizeof(slam_amd_dmatch), st))) return rc;
+    if ((rc = upload(m->h_k1, kp_q, (size_t)nq * sizeof(slam_amd_keypoint), st))) return rc;
+    if ((rc = upload(m->h_k2, kp_t, (size_t)nt * sizeof(slam_amd_keypoint), st))) return rc;
+    if ((rc = m->h_aux.reserve((size_t)n))) return rc;
+    OutlierArgs a;
+    memset(&a, 0, sizeof a);
+    a.xyz = m->h_xy.as<float>(); a.matches = m->h_out.as<slam_amd_dmatch>(); a.n = n;
+    a.kp_q = m->h_k1.as<slam_amd_keypoint>(); a.nq = nq;
+    a.kp_t = m->h_k2.as<slam_amd_keypoint>(); a.nt = nt;
+    for (int k = 0; k < 3; k++) { a.cq[k] = center_q[k]; a.ct[k] = center_t[k]; }
+    memcpy(a.cam_q.Rt, Rt_q, sizeof a.cam_q.Rt); memcpy(a.cam_q.K4, K4_q, sizeof a.cam_q.K4);
+    memcpy(a.cam_t.Rt, Rt_t, sizeof a.cam_t.Rt); memcpy(a.cam_t.K4, K4_t, sizeof a.cam_t.K4);
+    if (dist5_q) memcpy(a.cam_q.dist, dist5_q, sizeof a.cam_q.dist);
+    if (dist5_t) memcpy(a.cam_t.dist, dist5_t, sizeof a.cam_t.dist);
+    a.flags = m->h_aux.as<uint8_t>();
+    if ((rc = launch_outliers(a, st))) return rc;
+    SA_HIP(hipMemcpyAsync(flags, m->h_aux.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    SA_HIP(hipStreamSynchronize(st));
+    return SLAM_AMD_OK;
+}
+
 // =============================================================================
 // General
 // =============================================================================

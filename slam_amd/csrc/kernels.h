@@ -169,6 +169,21 @@ struct ProjectArgs {
     int n;
 };
 
+struct Camera {           // pose (row-major 3x4), fx fy cx cy, k1 k2 p1 p2 k3 of one keyframe
+    double Rt[12], K4[4], dist[5];
+};
+
+struct OutlierArgs {
+    const float* xyz;                  // [n][3] triangulated points
+    const slam_amd_dmatch* matches;    // [n]
+    int n;
+    const slam_amd_keypoint* kp_q; int nq;
+    const slam_amd_keypoint* kp_t; int nt;
+    float cq[3], ct[3];                // camera centres of the two keyframes
+    Camera cam_q, cam_t;
+    uint8_t* flags;                    // [n] 1 = outlier
+};
+
 struct DupArgs {
     const uint8_t* d1; const float* p1; int n1;
     const uint8_t* d2; const float* p2; int n2;
@@ -188,6 +203,7 @@ int window_splits(int batch, int nq_bound, int nt_bound, int n_cu);
 int launch_match_window(const WindowMatchArgs& a, int batch, int nq_bound, hipStream_t st);
 int launch_finalize(const FinalizeArgs& a, int batch, hipStream_t st);
 int launch_project(const ProjectArgs& a, hipStream_t st);
+int launch_outliers(const OutlierArgs& a, hipStream_t st);
 int launch_duplicates(const DupArgs& a, hipStream_t st);
 
 }  // namespace sa

@@ -314,13 +314,11 @@ __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) 
 
 // Pinhole projection with radial/tangential distortion, double arithmetic.
 
-__global__ __launch_bounds__(256) void project_kernel(ProjectArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
-    const double X = a.xyz[3 * i], Y = a.xyz[3 * i + 1], Z = a.xyz[3 * i + 2];
-    double x = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.Rt[0], X), __dmul_rn(a.Rt[1], Y)), __dmul_rn(a.Rt[2], Z)), a.Rt[3]);
-    double y = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.Rt[4], X), __dmul_rn(a.Rt[5], Y)), __dmul_rn(a.Rt[6], Z)), a.Rt[7]);
-    double z = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(a.Rt[8], X), __dmul_rn(a.Rt[9], Y)), __dmul_rn(a.Rt[10], Z)), a.Rt[11]);
+__device__ __forceinline__ float2 project_one(const double* Rt, const double* K4, const double* dist,
+                                              double X, double Y, double Z) {
+    double x = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(Rt[0], X), __dmul_rn(Rt[1], Y)), __dmul_rn(Rt[2], Z)), Rt[3]);
+    double y = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(Rt[4], X), __dmul_rn(Rt[5], Y)), __dmul_rn(Rt[6], Z)), Rt[7]);
+    double z = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(Rt[8], X), __dmul_rn(Rt[9], Y)), __dmul_rn(Rt[10], Z)), Rt[11]);
     z = z != 0.0 ? __ddiv_rn(1.0, z) : 1.0;
     x = __dmul_rn(x, z);
     y = __dmul_rn(y, z);
@@ -329,11 +327,55 @@ __global__ __launch_bounds__(256) void project_kernel(ProjectArgs a) {
     const double a1 = __dmul_rn(__dmul_rn(2.0, x), y);
     const double a2 = __dadd_rn(r2, __dmul_rn(__dmul_rn(2.0, x), x));
     const double a3 = __dadd_rn(r2, __dmul_rn(__dmul_rn(2.0, y), y));
-    const double cd = __dadd_rn(__dadd_rn(__dadd_rn(1.0, __dmul_rn(a.dist[0], r2)), __dmul_rn(a.dist[1], r4)), __dmul_rn(a.dist[4], r6));
-    const double xd = __dadd_rn(__dadd_rn(__dmul_rn(x, cd), __dmul_rn(a.dist[2], a1)), __dmul_rn(a.dist[3], a2));
-    const double yd = __dadd_rn(__dadd_rn(__dmul_rn(y, cd), __dmul_rn(a.dist[2], a3)), __dmul_rn(a.dist[3], a1));
-    a.uv[2 * i] = (float)__dadd_rn(__dmul_rn(xd, a.K4[0]), a.K4[2]);
-    a.uv[2 * i + 1] = (float)__dadd_rn(__dmul_rn(yd, a.K4[1]), a.K4[3]);
+    const double cd = __dadd_rn(__dadd_rn(__dadd_rn(1.0, __dmul_rn(dist[0], r2)), __dmul_rn(dist[1], r4)), __dmul_rn(dist[4], r6));
+    const double xd = __dadd_rn(__dadd_rn(__dmul_rn(x, cd), __dmul_rn(dist[2], a1)), __dmul_rn(dist[3], a2));
+    const double yd = __dadd_rn(__dadd_rn(__dmul_rn(y, cd), __dmul_rn(dist[2], a3)), __dmul_rn(dist[3], a1));
+    return make_float2((float)__dadd_rn(__dmul_rn(xd, K4[0]), K4[2]), (float)__dadd_rn(__dmul_rn(yd, K4[1]), K4[3]));
+}
+
+__global__ __launch_bounds__(256) void project_kernel(ProjectArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const float2 uv = project_one(a.Rt, a.K4, a.dist, a.xyz[3 * i], a.xyz[3 * i + 1], a.xyz[3 * i + 2]);
+    a.uv[2 * i] = uv.x;
+    a.uv[2 * i + 1] = uv.y;
+}
+
+// isOutlier of the reference for every triangulated point: NaN, parallax cosine outside
+// [0, 0.999f], within 1e-6 of a camera centre, or reprojected more than one pixel away
+// from its keypoint in either keyframe.  Float differences, double sums, as OpenCV's
+// Mat arithmetic on three-element CV_32F vectors does.
+__global__ __launch_bounds__(256) void outlier_kernel(OutlierArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const float X = a.xyz[3 * i], Y = a.xyz[3 * i + 1], Z = a.xyz[3 * i + 2];
+    const slam_amd_dmatch mt = a.matches[i];
+    uint8_t out = 1;
+    // indices were validated on the host for the blocking call; guard device callers too
+    const bool idx_ok = mt.queryIdx >= 0 && mt.queryIdx < a.nq && mt.trainIdx >= 0 && mt.trainIdx < a.nt;
+    if (idx_ok && !(X != X)) {
+        const float ax = __fsub_rn(X, a.cq[0]), ay = __fsub_rn(Y, a.cq[1]), az = __fsub_rn(Z, a.cq[2]);
+        const float bx = __fsub_rn(X, a.ct[0]), by = __fsub_rn(Y, a.ct[1]), bz = __fsub_rn(Z, a.ct[2]);
+        auto dot3 = [](float x0, float y0, float z0, float x1, float y1, float z1) {
+            return __dadd_rn(__dadd_rn(__dmul_rn((double)x0, (double)x1), __dmul_rn((double)y0, (double)y1)),
+                             __dmul_rn((double)z0, (double)z1));
+        };
+        const double dot = dot3(ax, ay, az, bx, by, bz);
+        const double na = __dsqrt_rn(dot3(ax, ay, az, ax, ay, az)), nb = __dsqrt_rn(dot3(bx, by, bz, bx, by, bz));
+        const double par = __ddiv_rn(dot, __dmul_rn(na, nb));
+        const bool par_bad = par < (double)0.0f || par > (double)0.999f;
+        const bool near = fabs(na) < 1E-6 || fabs(nb) < 1E-6;
+        if (!par_bad && !near) {
+            auto perr = [&](const Camera& c, float tx, float ty) {
+                const float2 uv = project_one(c.Rt, c.K4, c.dist, X, Y, Z);
+                const float dx = __fsub_rn(tx, uv.x), dy = __fsub_rn(ty, uv.y);
+                return __dsqrt_rn(__dadd_rn(__dmul_rn((double)dx, (double)dx), __dmul_rn((double)dy, (double)dy)));
+            };
+            const slam_amd_keypoint kq = a.kp_q[mt.queryIdx], kt = a.kp_t[mt.trainIdx];
+            if (!(perr(a.cam_q, kq.x, kq.y) > 1.0) && !(perr(a.cam_t, kt.x, kt.y) > 1.0)) out = 0;
+        }
+    }
+    a.flags[i] = out;
 }
 
 // Duplicate test of every (i, j): Hamming <= desc_dist and world distance < point_dist.
@@ -448,6 +490,13 @@ int launch_finalize(const FinalizeArgs& a, int batch, hipStream_t st) {
 int launch_project(const ProjectArgs& a, hipStream_t st) {
     if (a.n <= 0) return SLAM_AMD_OK;
     hipLaunchKernelGGL(project_kernel, dim3(div_up(a.n, 256)), dim3(256), 0, st, a);
+    SA_HIP(hipGetLastError());
+    return SLAM_AMD_OK;
+}
+
+int launch_outliers(const OutlierArgs& a, hipStream_t st) {
+    if (a.n <= 0) return SLAM_AMD_OK;
+    hipLaunchKernelGGL(outlier_kernel, dim3(div_up(a.n, 256)), dim3(256), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }

@@ -124,3 +124,18 @@ def noisy_copy(desc, flip_bits=20, seed=5):
         byte = rng.integers(0, 32, size=n); bit = rng.integers(0, 8, size=n)
         out[np.arange(n), byte] ^= (1 << bit).astype(np.uint8)
     return out
+
+
+def two_view_setup(n, seed):
+    """Two cameras looking down +z, points in front of both, exact keypoints = projections."""
+    rng = np.random.default_rng(seed)
+    K4 = np.array([520.0, 515.0, 320.0, 240.0])
+    Rt_q = np.hstack([np.eye(3), np.zeros((3, 1))])
+    ang = 0.05
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([[-0.4], [0.02], [0.01]])
+    Rt_t = np.hstack([R, t])
+    cq = np.zeros(3, np.float32)
+    ct = (-R.T @ t).ravel().astype(np.float32)
+    xyz = np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.7, 0.7, n), rng.uniform(2, 6, n)], 1).astype(np.float32)
+    return K4, Rt_q, Rt_t, cq, ct, xyz

@@ -557,3 +557,33 @@ def test_grid_distribution_option_known_properties(oracle):
     # grid off is the plain path
     k0, d0 = oracle.detect_and_compute(p, img, grid_cell=0)
     assert np.array_equal(k0, base)
+
+
+def test_outlier_flags_known_answers(oracle):
+    """isOutlier (src/map/mappoint.cpp:54-81): each rejection reason switched on in turn."""
+    n = 8
+    from slam_amd import synth
+    K4, Rt_q, Rt_t, cq, ct, xyz = synth.two_view_setup(n, 3)
+    kq = np.zeros(n, oracle.KEYPOINT_DTYPE); kt = np.zeros(n, oracle.KEYPOINT_DTYPE)
+    uvq = oracle.project_points(Rt_q, K4, None, xyz); uvt = oracle.project_points(Rt_t, K4, None, xyz)
+    kq["x"], kq["y"] = uvq[:, 0], uvq[:, 1]
+    kt["x"], kt["y"] = uvt[:, 0], uvt[:, 1]
+    m = np.zeros(n, oracle.DMATCH_DTYPE); m["queryIdx"] = np.arange(n); m["trainIdx"] = np.arange(n)[::-1]
+    kt = kt[::-1].copy()
+    args = (cq, ct, Rt_q, K4, None, Rt_t, K4, None)
+    assert not oracle.outlier_flags(xyz, m, kq, kt, *args).any()        # exact geometry: all inliers
+    bad = xyz.copy(); bad[0, 0] = np.nan                                 # NaN point
+    bad[1] = (0.0, 0.0, 400.0)                                           # rays almost parallel: cosine > 0.999f
+    bad[2] = ct + np.float32(1e-7)                                       # on a camera centre
+    bad[3] = (-0.2, 0.0, -0.001)                                         # between the cameras: negative cosine
+    f = oracle.outlier_flags(bad, m, kq, kt, *args)
+    assert f[:4].all() and not f[4:].any()
+    off = kq.copy(); off["x"][5] += 1.5                                  # reprojection error > 1 in the query view
+    assert oracle.outlier_flags(xyz, m, off, kt, *args).tolist() == [0, 0, 0, 0, 0, 1, 0, 0]
+    off = kt.copy(); off["y"][1] -= 0.9                                  # 0.9 px: still an inlier
+    assert not oracle.outlier_flags(xyz, m, kq, off, *args).any()
+    off["y"][1] -= 0.2                                                   # 1.1 px in the train view (match 6 -> train 1)
+    assert oracle.outlier_flags(xyz, m, kq, off, *args).tolist() == [0, 0, 0, 0, 0, 0, 1, 0]
+    with pytest.raises(ValueError):
+        m2 = m.copy(); m2["trainIdx"][0] = n
+        oracle.outlier_flags(xyz, m2, kq, kt, *args)
