@@ -294,6 +294,39 @@ public:
         return flag;
     }
 
+    // reference: isOutlier(point, queryKeyframe, trainKeyframe, match) for every point,
+    // src/map/mappoint.cpp:54-101 (called per point at src/tracking/mapper.cpp:48,121).
+    // flag != 0 = outlier.  Camera centres are -R^T t of each pose (KeyFrame::setPose,
+    // src/map/keyframe.cpp:19-22), products summed in double and rounded to float.
+    std::vector<uint8_t> outlierFlags(const std::vector<Point3f>& points, const std::vector<DMatch>& matches,
+                                      const KeyFrameView& queryKeyFrame, const KeyFrameView& trainKeyFrame) const {
+        if (points.size() != matches.size()) throw Error(SLAM_AMD_ERR_ARG, "one match per point");
+        std::vector<uint8_t> flags(points.size());
+        if (flags.empty()) return flags;
+        if (!queryKeyFrame.pose || !trainKeyFrame.pose) throw Error(SLAM_AMD_ERR_ARG, "both poses are needed");
+        double Rt[2][12], K4[2][4];
+        float centre[2][3];
+        const KeyFrameView* kf[2] = {&queryKeyFrame, &trainKeyFrame};
+        for (int v = 0; v < 2; v++) {
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 4; c++) Rt[v][r * 4 + c] = static_cast<double>(kf[v]->pose[r * 4 + c]);
+            for (int c = 0; c < 3; c++) {
+                double acc = 0;
+                for (int r = 0; r < 3; r++) acc += -Rt[v][r * 4 + c] * Rt[v][r * 4 + 3];
+                centre[v][c] = static_cast<float>(acc);
+            }
+            K4[v][0] = kf[v]->fx; K4[v][1] = kf[v]->fy; K4[v][2] = kf[v]->cx; K4[v][3] = kf[v]->cy;
+        }
+        check(slam_amd_outlier_flags(m_, &points[0].x, reinterpret_cast<const slam_amd_dmatch*>(matches.data()),
+                                     static_cast<int>(points.size()),
+                                     reinterpret_cast<const slam_amd_keypoint*>(queryKeyFrame.undistortedKeypoints),
+                                     queryKeyFrame.n,
+                                     reinterpret_cast<const slam_amd_keypoint*>(trainKeyFrame.undistortedKeypoints),
+                                     trainKeyFrame.n, centre[0], centre[1], Rt[0], K4[0], queryKeyFrame.distortions,
+                                     Rt[1], K4[1], trainKeyFrame.distortions, flags.data()));
+        return flags;
+    }
+
     // Not in the reference: Lowe's ratio test (nnRatio > 0) and the rotation-consistency
     // histogram (histoLength > 0, e.g. 30) applied to every later match call; see
     // slam_amd_matcher_set_options.  Both are off by default.

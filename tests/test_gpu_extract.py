@@ -49,25 +49,3 @@ def test_extract_main_cpp_params_odd_size(oracle, capi):
 def test_extract_kitti_shape(oracle, capi):
     img = synth.scene(1241, 376, 3)
     _compare(oracle, capi, img, 4000)
-
-
-@pytest.mark.parametrize("cell", [8, 16, 32])
-def test_grid_distribution_option_vs_oracle(oracle, capi, cell):
-    """Keypoint grid distribution (an option the reference does not have) against its oracle."""
-    for (w, h, nf, seed) in ((640, 480, 2000, 1), (333, 271, 500, 9)):
-        img = synth.scene(w, h, seed=seed)
-        po = oracle.params(nfeatures=nf)
-        ex = capi.Extractor(capi.orb_params(nfeatures=nf), w, h, max_batch=1, max_keypoints=8192)
-        ex.set_grid(cell)
-        kp_g, d_g = ex.extract(img)
-        kp_o, d_o = oracle.detect_and_compute(po, img, grid_cell=cell)
-        assert kp_g.tobytes() == kp_o.tobytes() and np.array_equal(d_g, d_o), (w, h, cell)
-        plain_o, _ = oracle.detect_and_compute(po, img)
-        assert len(kp_o) <= len(plain_o)
-        # off again: the reference's selection
-        ex.set_grid(0)
-        kp_g, d_g = ex.extract(img)
-        assert kp_g.tobytes() == plain_o.tobytes()
-        with pytest.raises(capi.SlamAmdError):
-            ex.set_grid(12)
-        ex.close()

@@ -386,33 +386,3 @@ def test_frame_pipeline_matches_sequential_oracle(oracle, capi):
             ref = oracle.match_gated(prev[1], prev[0], d_o, kp_o, 300.0, 50.0, 4)
             assert mt.tobytes() == ref.tobytes(), i
         prev = (kp_o, d_o)
-
-
-def test_outlier_flags_vs_oracle(oracle, capi):
-    """Batched isOutlier (src/map/mappoint.cpp:54-101) against the oracle, flag for flag."""
-    n = 5000
-    K4, Rt_q, Rt_t, cq, ct, xyz = synth.two_view_setup(n, 11)
-    rng = np.random.default_rng(12)
-    dist = np.array([0.05, -0.02, 0.001, -0.0005, 0.003])
-    uvq = oracle.project_points(Rt_q, K4, dist, xyz); uvt = oracle.project_points(Rt_t, K4, None, xyz)
-    kq = np.zeros(n, capi.KEYPOINT_DTYPE); kt = np.zeros(n, capi.KEYPOINT_DTYPE)
-    # keypoints scattered around the exact projections: errors on both sides of one pixel
-    kq["x"] = uvq[:, 0] + rng.normal(0, 0.6, n); kq["y"] = uvq[:, 1] + rng.normal(0, 0.6, n)
-    perm = rng.permutation(n)
-    kt["x"][perm] = uvt[:, 0] + rng.normal(0, 0.6, n); kt["y"][perm] = uvt[:, 1] + rng.normal(0, 0.6, n)
-    m_ = np.zeros(n, capi.DMATCH_DTYPE); m_["queryIdx"] = np.arange(n); m_["trainIdx"] = perm
-    pts = xyz.copy()
-    pts[rng.integers(0, n, 50), 0] = np.nan
-    pts[rng.integers(0, n, 50)] = (0.0, 0.0, 900.0)
-    pts[rng.integers(0, n, 20)] = ct
-    pts[rng.integers(0, n, 50), 2] *= -1
-    m = capi.Matcher()
-    got = m.outlier_flags(pts, m_, kq, kt, cq, ct, Rt_q, K4, dist, Rt_t, K4, None)
-    ref = oracle.outlier_flags(pts, m_, kq, kt, cq, ct, Rt_q, K4, dist, Rt_t, K4, None)
-    assert np.array_equal(got, ref)
-    assert 0.2 < ref.mean() < 0.9
-    with pytest.raises(capi.SlamAmdError):
-        bad = m_.copy(); bad["queryIdx"][7] = -1
-        m.outlier_flags(pts, bad, kq, kt, cq, ct, Rt_q, K4, dist, Rt_t, K4, None)
-    assert len(m.outlier_flags(pts[:0], m_[:0], kq, kt, cq, ct, Rt_q, K4, dist, Rt_t, K4, None)) == 0
-    m.close()
