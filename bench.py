@@ -3,7 +3,7 @@
 
 Primary line (one JSON object on stdout, rank 0): frames/s of ORB extraction +
 brute-force Hamming matching against the previous frame at 640x480, 2000
-features, 8 levels x 1.2 -- BASELINE.json configs[1].  A step is one batch of
+features, 8 levels x 1.2 -- the headline benchmark configuration.  A step is one batch of
 frames already resident in HBM: extract the batch, then match frame i against
 frame i-1 (the first frame of a batch against the last frame of the batch
 before).  With N > 1 every rank processes its own stream of frames (weak
@@ -13,7 +13,7 @@ The same line carries:
   roofline      the dominant kernel of the timed region, timed with HIP events
                 on the stream it runs on
   cpu_baseline  the CPU oracle (oracle/, 1 thread) on a bounded sample, rank 0, N = 1
-  extra         keyframe-pair matching (BASELINE.json configs[3]): all pairs of
+  extra         keyframe-pair matching (the multi-GPU benchmark configuration): all pairs of
                 --pair-keyframes x 2000 descriptors sharded over the ranks, results
                 gathered to rank 0 over RCCL, in Gcmp/s
 """
@@ -58,8 +58,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=60)
     ap.add_argument("--workload", default="frames", choices=["frames", "stream4k", "projection"],
-                    help="frames: BASELINE configs[1] (default, the driver's line); stream4k: configs[4]; "
-                         "projection: configs[2]")
+                    help="frames: 640x480 / 2000 features (default, the headline line); stream4k: 3840x2160 stream; "
+                         "projection: 1241x376, 20000 map points in a 50 px window")
     ap.add_argument("--stream-frames", type=int, default=300)
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a HIP graph replay")
     args = ap.parse_args()
@@ -303,7 +303,7 @@ def pmc_traffic(kernel, batch, width, height):
 
 
 def run_pairs(args, torch, dist, capi, synth, m, dev, rank, world, barrier):
-    """All i<j pairs of n_kf keyframes x n_per descriptors, gates off (BASELINE configs[3])."""
+    """All i<j pairs of n_kf keyframes x n_per descriptors, gates off (the multi-GPU benchmark configuration)."""
     from slam_amd import pairs as pairs_mod
     n_kf, n_per = args.pair_keyframes, args.pair_desc
     desc = synth.random_descriptors(n_kf * n_per, seed=3)
@@ -343,7 +343,7 @@ def run_pairs(args, torch, dist, capi, synth, m, dev, rank, world, barrier):
 
 
 def run_stream4k(args):
-    """BASELINE configs[4]: 3840x2160 stream, 10000 features, extract + match vs previous frame,
+    """4K stream configuration: 3840x2160 stream, 10000 features, extract + match vs previous frame,
     frames arriving in pinned host memory, H2D / compute / D2H overlapped on three streams."""
     import torch
     from slam_amd import capi, synth
@@ -397,7 +397,7 @@ def run_stream4k(args):
 
 
 def run_projection(args):
-    """BASELINE configs[2]: 1241x376 frames, 4000 features; 20000 map-point descriptors with
+    """KITTI-shaped configuration: 1241x376 frames, 4000 features; 20000 map-point descriptors with
     projected positions matched against the frame's keypoints, window 50 px, maxLevel 4."""
     import torch
     from slam_amd import capi, synth

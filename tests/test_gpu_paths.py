@@ -202,7 +202,7 @@ def test_match_edge_cases(oracle, capi):
 
 
 def test_projection_windowed_match_20k_vs_4k(oracle, capi):
-    """BASELINE configs[2] shape: 20000 map points with projected positions vs 4000 keypoints."""
+    """KITTI-shaped benchmark configuration: 20000 map points with projected positions vs 4000 keypoints."""
     d1, k1, d2, k2 = _sets(20000, 4000, 7, 1241, 376)
     rng = np.random.default_rng(9)
     q_xy = np.stack([k1["x"] + rng.normal(0, 5, 20000), k1["y"] + rng.normal(0, 5, 20000)], 1).astype(np.float32)
@@ -304,7 +304,7 @@ def test_match_pairs_vs_oracle(oracle, capi):
 
 
 def test_match_pairs_full_size_properties(capi):
-    """BASELINE configs[3] size per pair (2000 x 2000); checked by recomputation on samples."""
+    """Multi-GPU benchmark configuration, size per pair (2000 x 2000); checked by recomputation on samples."""
     torch = _torch()
     from slam_amd import pairs as pairs_mod
     n_kf, n_per = 24, 2000
