@@ -371,7 +371,38 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     uint8_t* smap = a.smap + (size_t)b * a.g.frame_bytes + L.off;
     const int edge = a.g.edge;
     const bool level_ok = (w > 2 * edge) && (h > 2 * edge);
-    {
+    if (!a.grid_shift) {
+        // the reference's selection: every NMS survivor inside the border goes on
+        const int tx = tid & 15, tr = tid >> 4;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int ly = tr + 16 * rr;
+            const int gy = y0 + ly;
+            if (gy >= h) continue;
+            const uint8_t* q0 = s_sc + (ly + 1) * kScPitch + 4 + 4 * tx;
+            const uint32_t own = *reinterpret_cast<const uint32_t*>(q0);
+            uint32_t packed = 0;
+            if (own != 0 && level_ok && gy >= edge && gy < h - edge) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int s = (own >> (8 * j)) & 255;
+                    const int gx = x0 + 4 * tx + j;
+                    if (s == 0 || gx < edge || gx >= w - edge) continue;
+                    const uint8_t* q = q0 + j;
+                    if (s > q[-1] && s > q[1] && s > q[-kScPitch - 1] && s > q[-kScPitch] &&
+                        s > q[-kScPitch + 1] && s > q[kScPitch - 1] && s > q[kScPitch] && s > q[kScPitch + 1]) {
+                        packed |= (uint32_t)s << (8 * j);
+                        atomicAdd(&s_hist[s], 1u);
+                        const size_t row = (size_t)b * a.g.total_rows + L.row_base + gy;
+                        const unsigned slot = atomicAdd(&a.rowfill[row], 1u);
+                        if (slot < (unsigned)a.g.rowcap)
+                            a.rowlist[row * kRowListCap + slot] = (uint32_t)gx | ((uint32_t)s << 16);
+                    }
+                }
+            }
+            *reinterpret_cast<uint32_t*>(smap + (size_t)gy * L.pitch + x0 + 4 * tx) = packed;
+        }
+    } else {
         const int tx = tid & 15, tr = tid >> 4;
         uint32_t keep[2] = {0u, 0u};   // NMS survivors of this thread's 4 pixels in rows tr and tr + 16
 #pragma unroll
@@ -400,7 +431,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         // cell of grid_cell x grid_cell pixels only the best stays -- highest score,
         // first in raster order among equals.  Cells are anchored at the level origin
         // and divide the tile, so the contest is local to the workgroup.
-        if (a.grid_shift) {
+        {
             const int sh = a.grid_shift;
             auto contest = [&](bool write) {
 #pragma unroll
