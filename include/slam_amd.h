@@ -259,6 +259,27 @@ int slam_amd_duplicate_pairs(slam_amd_matcher* m,
                              const uint8_t* desc2, const float* pos2, int n2,
                              int desc_dist, double point_dist, uint8_t* flag);
 
+/* ---------------------------------------------------------------------------
+ * Input front end: what main.cpp:124-129 does to every video frame before
+ * tracker.track() -- cv::cvtColor(BGR2GRAY), then cv::resize by
+ * scale = (float)target_width / (float)width (INTER_LINEAR, aspect kept) -- in one
+ * kernel.  channels = 3: interleaved BGR bytes; channels = 1: already grey (resize only).
+ * ------------------------------------------------------------------------- */
+typedef struct slam_amd_frontend slam_amd_frontend;
+int slam_amd_frontend_create(int src_width, int src_height, int channels, int target_width,
+                             int device, slam_amd_frontend** out);
+int slam_amd_frontend_destroy(slam_amd_frontend* fe);
+/* Size of the grey image: round(src * scale) per axis, as cv::resize computes it. */
+int slam_amd_frontend_output_size(const slam_amd_frontend* fe, int* width, int* height);
+/* Device pointers, asynchronous on `stream`; batch frames src_frame_pitch /
+ * dst_frame_pitch bytes apart.  The output can be handed to slam_amd_extract_batch_async. */
+int slam_amd_frontend_run_async(slam_amd_frontend* fe, const uint8_t* d_src, int batch,
+                                size_t src_frame_pitch, int src_row_stride,
+                                uint8_t* d_gray, size_t dst_frame_pitch, int dst_row_stride, void* stream);
+/* Host pointers, blocking, one frame. */
+int slam_amd_frontend_run(slam_amd_frontend* fe, const uint8_t* src, int src_row_stride,
+                          uint8_t* gray_out, int dst_row_stride);
+
 /* Host, blocking.  isOutlier of src/map/mappoint.cpp:54-81 (with projectionError,
  * :83-101) for n triangulated points at once, as Mapper calls it per point at
  * src/tracking/mapper.cpp:48 and :121.  Point i belongs to matches[i] (queryIdx into
@@ -294,6 +315,10 @@ void slam_amd_sincos_f32(float angle_rad, float* cos_out, float* sin_out);
 float slam_amd_fast_atan2(float y, float x);
 /* INTER_LINEAR_EXACT tables of one axis as the pyramid kernel receives them. */
 int slam_amd_linear_exact_coeffs(int src_size, int dst_size, int32_t* offsets, uint16_t* c1);
+/* Host-side table of cv::resize(INTER_LINEAR) for 8-bit images, one axis: source
+ * offset and the two 11-bit taps per destination index (clamp_frac: horizontal rule). */
+int slam_amd_linear_taps(int src_size, int dst_size, double inv_scale, int clamp_frac,
+                         int32_t* offsets, int16_t* taps);
 
 #ifdef __cplusplus
 }

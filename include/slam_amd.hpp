@@ -195,6 +195,43 @@ inline FrameData makeFrame(Detector& detector, const Image8& image, float distor
 }
 
 // ---------------------------------------------------------------------------
+// FrontEnd: the per-frame preparation of main.cpp:124-129 (cvtColor BGR2GRAY, then
+// resize to the working width), one kernel.  Created lazily per source size.
+// ---------------------------------------------------------------------------
+class FrontEnd {
+public:
+    explicit FrontEnd(int targetWidth, int device = 0) : target_(targetWidth), device_(device) {}
+    FrontEnd(const FrontEnd&) = delete;
+    FrontEnd& operator=(const FrontEnd&) = delete;
+    ~FrontEnd() { slam_amd_frontend_destroy(fe_); }
+
+    // bgr: rows x cols pixels of `channels` interleaved bytes (3 = BGR, 1 = grey).
+    // Returns the grey image, cols = round(cols * scale), rows = round(rows * scale).
+    std::vector<uint8_t> run(const uint8_t* data, int cols, int rows, size_t step, int channels,
+                             int* outCols, int* outRows) {
+        if (!data || cols <= 0 || rows <= 0) throw Error(SLAM_AMD_ERR_ARG, "empty frame");
+        if (!fe_ || cols != cols_ || rows != rows_ || channels != channels_) {
+            slam_amd_frontend_destroy(fe_);
+            fe_ = nullptr;
+            check(slam_amd_frontend_create(cols, rows, channels, target_, device_, &fe_));
+            cols_ = cols; rows_ = rows; channels_ = channels;
+        }
+        int w = 0, h = 0;
+        check(slam_amd_frontend_output_size(fe_, &w, &h));
+        std::vector<uint8_t> grey(static_cast<size_t>(w) * static_cast<size_t>(h));
+        check(slam_amd_frontend_run(fe_, data, static_cast<int>(step), grey.data(), w));
+        if (outCols) *outCols = w;
+        if (outRows) *outRows = h;
+        return grey;
+    }
+
+private:
+    int target_, device_;
+    slam_amd_frontend* fe_ = nullptr;
+    int cols_ = 0, rows_ = 0, channels_ = 0;
+};
+
+// ---------------------------------------------------------------------------
 // What Matcher reads from a slam::KeyFrame.
 // ---------------------------------------------------------------------------
 struct KeyFrameView {

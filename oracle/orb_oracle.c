@@ -493,6 +493,91 @@ int orc_detect_and_compute_grid(const orc_params* p, int grid_cell, const uint8_
     return ORC_OK;
 }
 
+/* ---------------------------------------------------------------------------
+ * Input front end of the reference's main loop (main.cpp:124-129):
+ * cv::cvtColor(BGR2GRAY) followed by cv::resize(Size(0,0), scale, scale) with the
+ * default INTER_LINEAR.  Restated from OpenCV 4.x: grey = (3735 B + 19235 G + 9798 R +
+ * 2^14) >> 15; resize with 11-bit fixed-point taps, the 8-bit vertical pass computing
+ * (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
+ * ------------------------------------------------------------------------- */
+int orc_bgr2gray(const uint8_t* bgr, int w, int h, int sstride, uint8_t* gray, int dstride) {
+    if (!bgr || !gray || w <= 0 || h <= 0) return ORC_ERR_ARG;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t* p = bgr + (size_t)y * sstride + 3 * x;
+            gray[(size_t)y * dstride + x] = (uint8_t)((3735 * p[0] + 19235 * p[1] + 9798 * p[2] + (1 << 14)) >> 15);
+        }
+    return ORC_OK;
+}
+
+int orc_resize_scale_size(int src_w, int src_h, float scale, int* dst_w, int* dst_h) {
+    if (!(scale > 0.f) || !dst_w || !dst_h) return ORC_ERR_ARG;
+    *dst_w = round_d((double)src_w * (double)scale);   /* saturate_cast<int>(double) rounds half to even */
+    *dst_h = round_d((double)src_h * (double)scale);
+    return (*dst_w > 0 && *dst_h > 0) ? ORC_OK : ORC_ERR_ARG;
+}
+
+/* Source offset and the two 11-bit taps of every destination index of one axis.
+ * clamp_frac: the horizontal pass clamps the fraction at the borders, the vertical
+ * pass clamps the row index instead and keeps the fraction. */
+int orc_linear_taps(int src_size, int dst_size, double inv_scale, int clamp_frac, int32_t* ofs, int16_t* taps) {
+    if (src_size <= 0 || dst_size <= 0 || !(inv_scale > 0) || !ofs || !taps) return ORC_ERR_ARG;
+    const double scale = 1.0 / inv_scale;
+    for (int d = 0; d < dst_size; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s0 = (int)floorf(f);
+        f -= (float)s0;
+        if (clamp_frac) {
+            if (s0 < 0) { f = 0.f; s0 = 0; }
+            if (s0 >= src_size - 1) { f = 0.f; s0 = src_size - 1; }
+        }
+        ofs[d] = s0;
+        taps[2 * d] = (int16_t)round_f((1.f - f) * 2048.f);
+        taps[2 * d + 1] = (int16_t)round_f(f * 2048.f);
+    }
+    return ORC_OK;
+}
+
+int orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride, float scale,
+                      uint8_t* dst, int dw, int dh, int dstride) {
+    int ew, eh;
+    int rc = orc_resize_scale_size(sw, sh, scale, &ew, &eh);
+    if (rc) return rc;
+    if (!src || !dst || ew != dw || eh != dh) return ORC_ERR_ARG;
+    int32_t* xo = (int32_t*)malloc(sizeof(int32_t) * dw); int16_t* xa = (int16_t*)malloc(sizeof(int16_t) * 2 * dw);
+    int32_t* yo = (int32_t*)malloc(sizeof(int32_t) * dh); int16_t* ya = (int16_t*)malloc(sizeof(int16_t) * 2 * dh);
+    if (!xo || !xa || !yo || !ya) { free(xo); free(xa); free(yo); free(ya); return ORC_ERR_NOMEM; }
+    orc_linear_taps(sw, dw, (double)scale, 1, xo, xa);
+    orc_linear_taps(sh, dh, (double)scale, 0, yo, ya);
+    for (int y = 0; y < dh; y++) {
+        int y0 = yo[y], y1 = yo[y] + 1;
+        y0 = y0 < 0 ? 0 : (y0 > sh - 1 ? sh - 1 : y0);
+        y1 = y1 < 0 ? 0 : (y1 > sh - 1 ? sh - 1 : y1);
+        const uint8_t* r0 = src + (size_t)y0 * sstride;
+        const uint8_t* r1 = src + (size_t)y1 * sstride;
+        for (int x = 0; x < dw; x++) {
+            const int x0 = xo[x], x1 = x0 + 1 < sw ? x0 + 1 : sw - 1;   /* second tap is 0 where x0 is the last column */
+            const int S0 = r0[x0] * xa[2 * x] + r0[x1] * xa[2 * x + 1];
+            const int S1 = r1[x0] * xa[2 * x] + r1[x1] * xa[2 * x + 1];
+            const int v = (((ya[2 * y] * (S0 >> 4)) >> 16) + ((ya[2 * y + 1] * (S1 >> 4)) >> 16) + 2) >> 2;
+            dst[(size_t)y * dstride + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+    free(xo); free(xa); free(yo); free(ya);
+    return ORC_OK;
+}
+
+int orc_frontend(const uint8_t* bgr, int w, int h, int sstride, int target_width,
+                 uint8_t* gray_out, int dw, int dh, int dstride) {
+    if (!bgr || !gray_out || w <= 0 || h <= 0 || target_width <= 0) return ORC_ERR_ARG;
+    uint8_t* g = (uint8_t*)malloc((size_t)w * h);
+    if (!g) return ORC_ERR_NOMEM;
+    int rc = orc_bgr2gray(bgr, w, h, sstride, g, w);
+    if (!rc) rc = orc_resize_linear(g, w, h, w, (float)target_width / (float)w, gray_out, dw, dh, dstride);
+    free(g);
+    return rc;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -194,6 +194,18 @@ int orc_duplicate_pairs(const uint8_t* d1, const float* p1, int n1,
                         const uint8_t* d2, const float* p2, int n2,
                         int desc_dist, double point_dist, uint8_t* flag);
 
+/* Input front end of the reference's main loop (main.cpp:124-129): BGR -> grey, then
+ * cv::resize by scale = (float)target_width / (float)width with INTER_LINEAR.  PARITY
+ * UNPINNED like the rest of the OpenCV side: restated from OpenCV 4.x (15-bit grey
+ * coefficients, 11-bit resize taps). */
+int orc_bgr2gray(const uint8_t* bgr, int w, int h, int sstride, uint8_t* gray, int dstride);
+int orc_resize_scale_size(int src_w, int src_h, float scale, int* dst_w, int* dst_h);
+int orc_linear_taps(int src_size, int dst_size, double inv_scale, int clamp_frac, int32_t* ofs, int16_t* taps);
+int orc_resize_linear(const uint8_t* src, int sw, int sh, int sstride, float scale,
+                      uint8_t* dst, int dw, int dh, int dstride);
+int orc_frontend(const uint8_t* bgr, int w, int h, int sstride, int target_width,
+                 uint8_t* gray_out, int dw, int dh, int dstride);
+
 /* Frame::Frame scale tables (src/frame/frame.cpp:28-37). */
 int orc_frame_scale_tables(float scale_factor, int nlevels, float* scales, float* sigma, float* inv_sigma);
 

@@ -280,6 +280,53 @@ def project_points(Rt, K4, dist5, xyz):
     return uv
 
 
+def frontend_size(w, h, target_width):
+    dw, dh = C.c_int(0), C.c_int(0)
+    rc = lib().orc_resize_scale_size(int(w), int(h), C.c_float(np.float32(target_width) / np.float32(w)),
+                                     C.byref(dw), C.byref(dh))
+    if rc: raise ValueError(rc)
+    return dw.value, dh.value
+
+
+def bgr2gray(bgr):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w, _ = bgr.shape
+    out = np.zeros((h, w), np.uint8)
+    rc = lib().orc_bgr2gray(_p(bgr), w, h, bgr.strides[0], _p(out), w)
+    if rc: raise ValueError(rc)
+    return out
+
+
+def resize_linear(gray, scale):
+    gray = _img(gray)
+    h, w = gray.shape
+    dw, dh = C.c_int(0), C.c_int(0)
+    lib().orc_resize_scale_size(w, h, C.c_float(scale), C.byref(dw), C.byref(dh))
+    out = np.zeros((dh.value, dw.value), np.uint8)
+    rc = lib().orc_resize_linear(_p(gray), w, h, gray.strides[0], C.c_float(scale), _p(out), dw.value, dh.value, dw.value)
+    if rc: raise ValueError(rc)
+    return out
+
+
+def linear_taps(src_size, dst_size, inv_scale, clamp_frac):
+    ofs = np.zeros(dst_size, np.int32); taps = np.zeros((dst_size, 2), np.int16)
+    lib().orc_linear_taps.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    rc = lib().orc_linear_taps(src_size, dst_size, float(inv_scale), int(clamp_frac), _p(ofs), _p(taps))
+    if rc: raise ValueError(rc)
+    return ofs, taps
+
+
+def frontend(bgr, target_width):
+    """main.cpp:124-129: BGR frame -> grey -> resized to target_width (aspect kept)."""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w, _ = bgr.shape
+    dw, dh = frontend_size(w, h, target_width)
+    out = np.zeros((dh, dw), np.uint8)
+    rc = lib().orc_frontend(_p(bgr), w, h, bgr.strides[0], int(target_width), _p(out), dw, dh, dw)
+    if rc: raise ValueError(rc)
+    return out
+
+
 def outlier_flags(xyz, matches, kp_q, kp_t, center_q, center_t, Rt_q, K4_q, dist5_q, Rt_t, K4_t, dist5_t):
     xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
     matches = np.ascontiguousarray(matches, DMATCH_DTYPE)

@@ -35,6 +35,8 @@ EXPORTS = [
     "slam_amd_match_pairs_async",
     "slam_amd_project_points", "slam_amd_project_points_async", "slam_amd_duplicate_pairs",
     "slam_amd_outlier_flags",
+    "slam_amd_frontend_create", "slam_amd_frontend_destroy", "slam_amd_frontend_output_size",
+    "slam_amd_frontend_run_async", "slam_amd_frontend_run", "slam_amd_linear_taps",
     "slam_amd_prof_enable", "slam_amd_prof_collect", "slam_amd_prof_stage_name",
     "slam_amd_sincos_f32", "slam_amd_fast_atan2", "slam_amd_linear_exact_coeffs",
 ]
@@ -142,6 +144,13 @@ def _ptr(a):
     raise TypeError(type(a))
 
 
+def linear_taps(src_size, dst_size, inv_scale, clamp_frac):
+    ofs = np.zeros(dst_size, np.int32); taps = np.zeros((dst_size, 2), np.int16)
+    lib().slam_amd_linear_taps.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    check(lib().slam_amd_linear_taps(src_size, dst_size, float(inv_scale), int(clamp_frac), _ptr(ofs), _ptr(taps)))
+    return ofs, taps
+
+
 def sincos_f32(angle_rad):
     c = C.c_float(); s = C.c_float()
     lib().slam_amd_sincos_f32(C.c_float(angle_rad), C.byref(c), C.byref(s))
@@ -240,6 +249,49 @@ class Extractor:
         fn = lib().slam_amd_extractor_debug_blurred_level if blurred else lib().slam_amd_extractor_debug_level
         check(fn(self._h, frame, level, _ptr(out), int(ws[level])))
         return out
+
+
+class Frontend:
+    """BGR (or grey) frame -> grey frame of the working width: cvtColor + resize of main.cpp:124-129."""
+
+    def __init__(self, src_width, src_height, target_width, channels=3, device=0):
+        self._h = C.c_void_p()
+        l = lib()
+        l.slam_amd_frontend_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        l.slam_amd_frontend_destroy.argtypes = [C.c_void_p]
+        l.slam_amd_frontend_output_size.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        l.slam_amd_frontend_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        l.slam_amd_frontend_run_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int,
+                                                  C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        check(l.slam_amd_frontend_create(src_width, src_height, channels, target_width, device, C.byref(self._h)))
+        self.src_width, self.src_height, self.channels = src_width, src_height, channels
+        w, h = C.c_int(0), C.c_int(0)
+        check(l.slam_amd_frontend_output_size(self._h, C.byref(w), C.byref(h)))
+        self.width, self.height = w.value, h.value
+
+    def close(self):
+        if self._h:
+            lib().slam_amd_frontend_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, frame):
+        """Host, blocking: numpy [h, w, 3] (or [h, w]) uint8 in, grey [height, width] out."""
+        frame = np.ascontiguousarray(frame, np.uint8)
+        assert frame.shape[0] == self.src_height and frame.shape[1] == self.src_width
+        out = np.zeros((self.height, self.width), np.uint8)
+        check(lib().slam_amd_frontend_run(self._h, _ptr(frame), frame.strides[0], _ptr(out), self.width))
+        return out
+
+    def run_async(self, d_src, batch, src_frame_pitch, src_row_stride, d_gray, dst_frame_pitch, dst_row_stride,
+                  stream=0):
+        check(lib().slam_amd_frontend_run_async(self._h, _ptr(d_src), batch, src_frame_pitch, src_row_stride,
+                                                _ptr(d_gray), dst_frame_pitch, dst_row_stride, _ptr(stream)))
 
 
 class Matcher:

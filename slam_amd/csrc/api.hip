@@ -830,6 +830,136 @@ extern "C" int slam_amd_outlier_flags(slam_amd_matcher* m, const float* xyz, con
 }
 
 // =============================================================================
+// Input front end (BGR -> grey -> bilinear resize to the working width)
+// =============================================================================
+struct slam_amd_frontend {
+    int device = 0;
+    int sw = 0, sh = 0, channels = 3, dw = 0, dh = 0;
+    hipStream_t stream = nullptr;
+    DevBuf tables;       // xofs, yofs (int32), xtap, ytap (int16 pairs)
+    size_t o_xofs = 0, o_yofs = 0, o_xtap = 0, o_ytap = 0;
+    DevBuf h_src, h_dst; // staging of the host call
+};
+
+// Source offset and 11-bit taps of one axis, as cv::resize(INTER_LINEAR) builds them
+// for 8-bit images: f = (float)((d + 0.5) / inv_scale - 0.5), taps = round((1 - f, f) * 2048).
+static void linear_taps_axis(int src, int dst, double inv_scale, bool clamp_frac, int32_t* ofs, int16_t* taps) {
+    const double scale = 1.0 / inv_scale;
+    for (int d = 0; d < dst; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s0 = (int)floorf(f);
+        f -= (float)s0;
+        if (clamp_frac) {
+            if (s0 < 0) { f = 0.f; s0 = 0; }
+            if (s0 >= src - 1) { f = 0.f; s0 = src - 1; }
+        }
+        ofs[d] = s0;
+        taps[2 * d] = (int16_t)lrintf((1.f - f) * 2048.f);
+        taps[2 * d + 1] = (int16_t)lrintf(f * 2048.f);
+    }
+}
+
+extern "C" int slam_amd_frontend_create(int src_width, int src_height, int channels, int target_width,
+                                        int device, slam_amd_frontend** out) {
+    if (!out) SA_FAIL(SLAM_AMD_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (src_width <= 0 || src_height <= 0 || target_width <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "sizes must be positive");
+    if (src_width > 32768 || src_height > 32768 || target_width > 32768) SA_FAIL(SLAM_AMD_ERR_ARG, "size above 32768");
+    if (channels != 1 && channels != 3) SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "1 (grey) or 3 (BGR) channels");
+    int rc = use_device(device);
+    if (rc) return rc;
+    // scale as main.cpp:125-128 computes it, destination size as cv::resize does
+    const float scale = (float)target_width / (float)src_width;
+    const int dw = (int)lrint((double)src_width * (double)scale);
+    const int dh = (int)lrint((double)src_height * (double)scale);
+    if (dw <= 0 || dh <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "the scaled image is empty");
+    slam_amd_frontend* fe = new (std::nothrow) slam_amd_frontend();
+    if (!fe) SA_FAIL(SLAM_AMD_ERR_NOMEM, "out of host memory");
+    fe->device = device; fe->sw = src_width; fe->sh = src_height; fe->channels = channels; fe->dw = dw; fe->dh = dh;
+    auto fail = [&](int code) { slam_amd_frontend_destroy(fe); return code; };
+    std::vector<int32_t> xofs((size_t)dw), yofs((size_t)dh);
+    std::vector<int16_t> xtap((size_t)dw * 2), ytap((size_t)dh * 2);
+    linear_taps_axis(src_width, dw, (double)scale, true, xofs.data(), xtap.data());
+    linear_taps_axis(src_height, dh, (double)scale, false, yofs.data(), ytap.data());
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    fe->o_xofs = 0;
+    fe->o_yofs = up(fe->o_xofs + xofs.size() * 4);
+    fe->o_xtap = up(fe->o_yofs + yofs.size() * 4);
+    fe->o_ytap = up(fe->o_xtap + xtap.size() * 2);
+    const size_t total = up(fe->o_ytap + ytap.size() * 2);
+    if ((rc = fe->tables.reserve(total))) return fail(rc);
+    uint8_t* t = fe->tables.as<uint8_t>();
+    if (hipMemcpy(t + fe->o_xofs, xofs.data(), xofs.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(t + fe->o_yofs, yofs.data(), yofs.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(t + fe->o_xtap, xtap.data(), xtap.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(t + fe->o_ytap, ytap.data(), ytap.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("hipMemcpy of the resize tables failed");
+        return fail(SLAM_AMD_ERR_HIP);
+    }
+    hipError_t e = hipStreamCreateWithFlags(&fe->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { slam_amd_frontend_destroy(fe); return hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__); }
+    *out = fe;
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_frontend_destroy(slam_amd_frontend* fe) {
+    if (!fe) return SLAM_AMD_OK;
+    (void)hipSetDevice(fe->device);
+    if (fe->stream) { (void)hipStreamSynchronize(fe->stream); (void)hipStreamDestroy(fe->stream); }
+    fe->tables.release(); fe->h_src.release(); fe->h_dst.release();
+    delete fe;
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_frontend_output_size(const slam_amd_frontend* fe, int* width, int* height) {
+    if (!fe || !width || !height) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    *width = fe->dw; *height = fe->dh;
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_frontend_run_async(slam_amd_frontend* fe, const uint8_t* d_src, int batch,
+                                           size_t src_frame_pitch, int src_row_stride,
+                                           uint8_t* d_gray, size_t dst_frame_pitch, int dst_row_stride,
+                                           void* stream) {
+    if (!fe || !d_src || !d_gray) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    if (batch <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "batch must be positive");
+    if (src_row_stride < fe->sw * fe->channels) SA_FAIL(SLAM_AMD_ERR_ARG, "source row stride smaller than a row");
+    if (dst_row_stride < fe->dw) SA_FAIL(SLAM_AMD_ERR_ARG, "destination row stride smaller than a row");
+    if (batch > 1 && (src_frame_pitch < (size_t)src_row_stride * (fe->sh - 1) + (size_t)fe->sw * fe->channels ||
+                      dst_frame_pitch < (size_t)dst_row_stride * (fe->dh - 1) + fe->dw))
+        SA_FAIL(SLAM_AMD_ERR_ARG, "frame pitch smaller than one frame");
+    SA_HIP(hipSetDevice(fe->device));
+    FrontendArgs a;
+    memset(&a, 0, sizeof a);
+    a.src = d_src; a.src_frame_pitch = src_frame_pitch; a.src_pitch = src_row_stride;
+    a.sw = fe->sw; a.sh = fe->sh; a.channels = fe->channels;
+    a.dst = d_gray; a.dst_frame_pitch = dst_frame_pitch; a.dst_pitch = dst_row_stride; a.dw = fe->dw; a.dh = fe->dh;
+    const uint8_t* t = fe->tables.as<uint8_t>();
+    a.xofs = reinterpret_cast<const int32_t*>(t + fe->o_xofs); a.yofs = reinterpret_cast<const int32_t*>(t + fe->o_yofs);
+    a.xtap = reinterpret_cast<const int16_t*>(t + fe->o_xtap); a.ytap = reinterpret_cast<const int16_t*>(t + fe->o_ytap);
+    return launch_frontend(a, batch, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int slam_amd_frontend_run(slam_amd_frontend* fe, const uint8_t* src, int src_row_stride,
+                                     uint8_t* gray_out, int dst_row_stride) {
+    if (!fe || !src || !gray_out) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    if (src_row_stride < fe->sw * fe->channels) SA_FAIL(SLAM_AMD_ERR_ARG, "source row stride smaller than a row");
+    if (dst_row_stride < fe->dw) SA_FAIL(SLAM_AMD_ERR_ARG, "destination row stride smaller than a row");
+    SA_HIP(hipSetDevice(fe->device));
+    const size_t row = (size_t)fe->sw * fe->channels;
+    int rc;
+    if ((rc = fe->h_src.reserve(row * fe->sh))) return rc;
+    if ((rc = fe->h_dst.reserve((size_t)fe->dw * fe->dh))) return rc;
+    SA_HIP(hipMemcpy2DAsync(fe->h_src.p, row, src, src_row_stride, row, fe->sh, hipMemcpyHostToDevice, fe->stream));
+    rc = slam_amd_frontend_run_async(fe, fe->h_src.as<uint8_t>(), 1, row * fe->sh, (int)row, fe->h_dst.as<uint8_t>(),
+                                     (size_t)fe->dw * fe->dh, fe->dw, fe->stream);
+    if (rc) return rc;
+    SA_HIP(hipMemcpy2DAsync(gray_out, dst_row_stride, fe->h_dst.p, fe->dw, fe->dw, fe->dh, hipMemcpyDeviceToHost, fe->stream));
+    SA_HIP(hipStreamSynchronize(fe->stream));
+    return SLAM_AMD_OK;
+}
+
+// =============================================================================
 // General
 // =============================================================================
 extern "C" int slam_amd_prof_enable(int max_marks) {
@@ -903,6 +1033,13 @@ extern "C" void slam_amd_sincos_f32(float angle_rad, float* cos_out, float* sin_
 }
 
 extern "C" float slam_amd_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
+
+extern "C" int slam_amd_linear_taps(int src_size, int dst_size, double inv_scale, int clamp_frac,
+                                    int32_t* offsets, int16_t* taps) {
+    if (src_size <= 0 || dst_size <= 0 || !(inv_scale > 0) || !offsets || !taps) SA_FAIL(SLAM_AMD_ERR_ARG, "bad argument");
+    linear_taps_axis(src_size, dst_size, inv_scale, clamp_frac != 0, offsets, taps);
+    return SLAM_AMD_OK;
+}
 
 extern "C" int slam_amd_linear_exact_coeffs(int src_size, int dst_size, int32_t* offsets, uint16_t* c1) {
     if (src_size <= 0 || dst_size <= 0 || !offsets || !c1) SA_FAIL(SLAM_AMD_ERR_ARG, "bad argument");

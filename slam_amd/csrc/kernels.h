@@ -184,6 +184,19 @@ struct OutlierArgs {
     uint8_t* flags;                    // [n] 1 = outlier
 };
 
+struct FrontendArgs {
+    const uint8_t* src;        // [batch] frames, `channels` interleaved bytes per pixel (3 = BGR, 1 = grey)
+    size_t src_frame_pitch;
+    int src_pitch, sw, sh, channels;
+    uint8_t* dst;              // [batch] grey frames
+    size_t dst_frame_pitch;
+    int dst_pitch, dw, dh;
+    const int32_t* xofs;       // [dw] source column, clamped to [0, sw - 1]
+    const int16_t* xtap;       // [dw][2] 11-bit taps
+    const int32_t* yofs;       // [dh] source row, may be -1 .. sh - 1 (clamped in the kernel)
+    const int16_t* ytap;       // [dh][2]
+};
+
 struct DupArgs {
     const uint8_t* d1; const float* p1; int n1;
     const uint8_t* d2; const float* p2; int n2;
@@ -203,6 +216,7 @@ int window_splits(int batch, int nq_bound, int nt_bound, int n_cu);
 int launch_match_window(const WindowMatchArgs& a, int batch, int nq_bound, hipStream_t st);
 int launch_finalize(const FinalizeArgs& a, int batch, hipStream_t st);
 int launch_project(const ProjectArgs& a, hipStream_t st);
+int launch_frontend(const FrontendArgs& a, int batch, hipStream_t st);
 int launch_outliers(const OutlierArgs& a, hipStream_t st);
 int launch_duplicates(const DupArgs& a, hipStream_t st);
 

@@ -119,3 +119,15 @@ def test_pair_sharding_covers_every_pair_once():
             edges = [pairs.chunk_rows(per, chunks, c) for c in range(chunks)]
             assert edges[0][0] == 0 and edges[-1][1] == per
             assert all(edges[i][1] == edges[i + 1][0] for i in range(chunks - 1))
+
+
+def test_frontend_resize_tables_match_oracle(oracle):
+    """The library builds the cv::resize(INTER_LINEAR) tables on the host; same bits as the oracle."""
+    from slam_amd import capi
+    for src, dst_w in ((1920, 1080), (1280, 1080), (640, 1080), (123, 77), (3840, 640)):
+        sc = np.float32(dst_w) / np.float32(src)
+        dst = int(np.rint(src * np.float64(sc)))
+        for clamp in (0, 1):
+            o1, t1 = capi.linear_taps(src, dst, float(sc), clamp)
+            o2, t2 = oracle.linear_taps(src, dst, float(sc), clamp)
+            assert np.array_equal(o1, o2) and np.array_equal(t1, t2), (src, dst_w, clamp)

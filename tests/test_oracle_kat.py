@@ -587,3 +587,47 @@ def test_outlier_flags_known_answers(oracle):
     with pytest.raises(ValueError):
         m2 = m.copy(); m2["trainIdx"][0] = n
         oracle.outlier_flags(xyz, m2, kq, kt, *args)
+
+
+def test_frontend_grey_and_linear_resize_known_answers(oracle):
+    """main.cpp:124-129 restated: grey weights, resize taps and the two-pass fixed-point formula."""
+    rng = np.random.default_rng(4)
+    # grey: pure channels and the rounding constant
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [1, 1, 1], [10, 200, 33]]], np.uint8)
+    want = [(3735 * b + 19235 * g + 9798 * r + 16384) >> 15 for b, g, r in px[0].tolist()]
+    assert oracle.bgr2gray(px)[0].tolist() == want == [29, 150, 76, 255, 1, 128]
+    # scale 1: every fraction is 0, the resize is a copy
+    g = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    assert np.array_equal(oracle.resize_linear(g, np.float32(1.0)), g)
+    # a constant image stays constant at any scale
+    c = np.full((40, 60), 201, np.uint8)
+    for sc in (0.3, 0.5625, 0.77, 1.7):
+        out = oracle.resize_linear(c, np.float32(sc))
+        assert out.shape == (int(np.rint(40 * np.float64(np.float32(sc)))), int(np.rint(60 * np.float64(np.float32(sc)))))
+        assert (out == 201).all()
+    # taps: sum to 2048, offsets monotone, borders clamped horizontally only
+    ofs, taps = oracle.linear_taps(1920, 1080, float(np.float32(1080) / np.float32(1920)), 1)
+    assert (taps.sum(1) == 2048).all() and (np.diff(ofs) >= 0).all() and ofs.min() >= 0 and ofs.max() <= 1919
+    ofs_y, taps_y = oracle.linear_taps(100, 30, 0.3, 0)
+    assert ofs_y[0] == 1 and ofs_y[-1] <= 99
+    ofs_u, taps_u = oracle.linear_taps(10, 25, 2.5, 0)     # upscaling: the first row lies above the image
+    assert ofs_u[0] == -1 and taps_u[0].tolist() == [614, 1434]
+    ofs_c, taps_c = oracle.linear_taps(10, 25, 2.5, 1)
+    assert ofs_c[0] == 0 and taps_c[0].tolist() == [2048, 0] and ofs_c[-1] == 9 and taps_c[-1].tolist() == [2048, 0]
+    # the whole resize against an independent numpy restatement
+    g = rng.integers(0, 256, (91, 123), dtype=np.uint8)
+    for sc in (np.float32(0.5625), np.float32(0.37), np.float32(1.31)):
+        dh, dw = int(np.rint(91 * np.float64(sc))), int(np.rint(123 * np.float64(sc)))
+        xo, xa = oracle.linear_taps(123, dw, float(sc), 1)
+        yo, ya = oracle.linear_taps(91, dh, float(sc), 0)
+        x1 = np.minimum(xo + 1, 122)
+        rows = g.astype(np.int64)
+        H = rows[:, xo] * xa[:, 0].astype(np.int64) + rows[:, x1] * xa[:, 1].astype(np.int64)   # [91][dw]
+        y0 = np.clip(yo, 0, 90); y1 = np.clip(yo + 1, 0, 90)
+        v = (((ya[:, :1].astype(np.int64) * (H[y0] >> 4)) >> 16) + ((ya[:, 1:].astype(np.int64) * (H[y1] >> 4)) >> 16) + 2) >> 2
+        assert np.array_equal(oracle.resize_linear(g, sc), np.clip(v, 0, 255).astype(np.uint8)), sc
+    # front end = grey then resize, size as cv::resize computes it
+    bgr = rng.integers(0, 256, (72, 128, 3), dtype=np.uint8)
+    out = oracle.frontend(bgr, 96)
+    assert out.shape == (54, 96)
+    assert np.array_equal(out, oracle.resize_linear(oracle.bgr2gray(bgr), np.float32(96) / np.float32(128)))

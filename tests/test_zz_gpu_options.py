@@ -60,3 +60,41 @@ def test_outlier_flags_vs_oracle(oracle, capi):
         m.outlier_flags(pts, bad, kq, kt, cq, ct, Rt_q, K4, dist, Rt_t, K4, None)
     assert len(m.outlier_flags(pts[:0], m_[:0], kq, kt, cq, ct, Rt_q, K4, dist, Rt_t, K4, None)) == 0
     m.close()
+
+
+def test_frontend_grey_resize_vs_oracle(oracle, capi):
+    """cvtColor + resize of main.cpp:124-129 in one kernel, against the two-step oracle."""
+    import torch
+    rng = np.random.default_rng(21)
+    for (w, h, target, ch) in ((1920, 1080, 1080, 3), (1280, 720, 1080, 3), (333, 251, 640, 3), (640, 480, 400, 1)):
+        frame = rng.integers(0, 256, (h, w, ch), dtype=np.uint8) if ch == 3 else rng.integers(0, 256, (h, w), dtype=np.uint8)
+        # smooth structure as well as noise
+        yy, xx = np.mgrid[0:h, 0:w]
+        ramp = ((xx * 3 + yy * 2) % 256).astype(np.uint8)
+        if ch == 3:
+            frame[..., 1] = ramp
+        fe = capi.Frontend(w, h, target, channels=ch)
+        ref = oracle.frontend(frame, target) if ch == 3 else oracle.resize_linear(frame, np.float32(target) / np.float32(w))
+        assert (fe.height, fe.width) == ref.shape
+        got = fe.run(frame)
+        assert np.array_equal(got, ref), (w, h, target, ch)
+        # device path, two frames with padded strides
+        B = 2
+        sp = w * ch + 5
+        src = torch.zeros((B, h, sp), dtype=torch.uint8, device="cuda")
+        flat = torch.from_numpy(frame.reshape(h, w * ch)).cuda()
+        src[0, :, : w * ch] = flat
+        src[1, :, : w * ch] = torch.flip(flat, dims=[0])
+        dp = fe.width + 3
+        dst = torch.zeros((B, fe.height, dp), dtype=torch.uint8, device="cuda")
+        fe.run_async(src, B, h * sp, sp, dst, fe.height * dp, dp, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out = dst.cpu().numpy()
+        assert np.array_equal(out[0, :, : fe.width], ref)
+        flipped = frame[::-1].copy()
+        ref1 = oracle.frontend(flipped, target) if ch == 3 else oracle.resize_linear(flipped, np.float32(target) / np.float32(w))
+        assert np.array_equal(out[1, :, : fe.width], ref1)
+        assert (out[:, :, fe.width:] == 0).all()
+        fe.close()
+    with pytest.raises(capi.SlamAmdError):
+        capi.Frontend(640, 480, 320, channels=4)
