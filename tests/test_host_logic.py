@@ -131,3 +131,20 @@ def test_frontend_resize_tables_match_oracle(oracle):
             o1, t1 = capi.linear_taps(src, dst, float(sc), clamp)
             o2, t2 = oracle.linear_taps(src, dst, float(sc), clamp)
             assert np.array_equal(o1, o2) and np.array_equal(t1, t2), (src, dst_w, clamp)
+
+
+def test_frontend_arguments_are_checked_before_touching_the_gpu(capi):
+    for args, status in (((0, 480, 320, 3), capi.ERR_ARG), ((640, 480, 0, 3), capi.ERR_ARG),
+                         ((40000, 480, 320, 3), capi.ERR_ARG), ((640, 480, 320, 4), capi.ERR_UNSUPPORTED),
+                         ((640, 480, 320, 2), capi.ERR_UNSUPPORTED)):
+        with pytest.raises(capi.SlamAmdError) as e:
+            capi.Frontend(args[0], args[1], args[2], channels=args[3])
+        assert e.value.status == status, args
+    if capi.device_count() == 0:
+        with pytest.raises(capi.SlamAmdError) as e:
+            capi.Frontend(1920, 1080, 1080)
+        assert e.value.status == capi.ERR_NO_DEVICE
+    with pytest.raises(capi.SlamAmdError):
+        capi.linear_taps(0, 10, 0.5, 1)
+    with pytest.raises(capi.SlamAmdError):
+        capi.linear_taps(10, 10, -1.0, 1)
