@@ -9,18 +9,27 @@ frame i-1 (the first frame of a batch against the last frame of the batch
 before).  With N > 1 every rank processes its own stream of frames (weak
 scaling, no data-path collective).
 
+`python bench.py --gpus N` starts its own N ranks (one process per GPU) when it was not
+started by torch.distributed.run; under torch.distributed.run it is one of the ranks.
+
 The same line carries:
   roofline      the dominant kernel of the timed region, timed with HIP events
                 on the stream it runs on
   cpu_baseline  the CPU oracle (oracle/, 1 thread) on a bounded sample, rank 0, N = 1
-  extra         keyframe-pair matching (the multi-GPU benchmark configuration): all pairs of
+  extra         the same step with the ratio test on; the same step with frames arriving in
+                pinned host memory (H2D and D2H overlapped with compute); keyframe-pair
+                matching (the multi-GPU benchmark configuration): all pairs of
                 --pair-keyframes x 2000 descriptors sharded over the ranks, results
                 gathered to rank 0 over RCCL, in Gcmp/s
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -30,22 +39,32 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
-# Integer ceiling of a 256-bit Hamming compare on gfx950, measured with tools/valu_peak.hip
-# (8 v_xor + 8 chained v_bcnt, operands in registers, nothing else running): v_bcnt issues at
-# half rate, so the ceiling is far below the 4914 Gcmp/s of "16 full-rate ops per compare".
-VALU_PEAK_GCMP = 2638.0
+CLOCK_GHZ = 2.4
+N_SIMD = 1024                  # 256 CUs x 4 SIMD-32; a wave64 VALU instruction holds one for 2 cycles
 VALU_NOMINAL_GCMP = 4914.0     # 256 CU x 128 lanes/clk x 2.4 GHz / 16 ops, for reference only
+
+
+def valu_peak_gcmp():
+    """Integer ceiling of a 256-bit Hamming compare on gfx950 in Gcmp/s, read from the committed
+    output of tools/valu_peak.hip (8 v_xor + 8 chained v_bcnt per compare, operands in registers,
+    nothing else running): v_bcnt issues at half rate, so the ceiling is far below the nominal
+    "16 full-rate ops per compare" figure."""
+    path = os.path.join(ROOT, "profiles", "valu_peak.json")
+    with open(path) as f:
+        return float(json.load(f)["hamming256_gcmp_per_s"])
 
 
 def pyramid_pixels(ws, hs):
     return [int(w) * int(h) for w, h in zip(ws, hs)]
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (exactly --steps steps) is run this many times; the line reports the median")
     ap.add_argument("--batch", type=int, default=64, help="frames per step and GPU")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -54,47 +73,175 @@ def main():
     ap.add_argument("--pair-keyframes", type=int, default=1024)
     ap.add_argument("--pair-desc", type=int, default=2000)
     ap.add_argument("--pair-chunks", type=int, default=16)
+    ap.add_argument("--pair-deadline", type=float, default=240.0,
+                    help="seconds after which the line is printed without the keyframe-pair leg")
     ap.add_argument("--no-pairs", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the ratio-test and host-pipelined variants")
     ap.add_argument("--cpu-frames", type=int, default=60)
     ap.add_argument("--workload", default="frames", choices=["frames", "stream4k", "projection"],
                     help="frames: 640x480 / 2000 features (default, the headline line); stream4k: 3840x2160 stream; "
                          "projection: 1241x376, 20000 map points in a 50 px window")
     ap.add_argument("--stream-frames", type=int, default=300)
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a HIP graph replay")
-    args = ap.parse_args()
+    ap.add_argument("--graph-order", default="late", choices=["early", "late"],
+                    help="early: both graphs (batch, single frame) are captured and instantiated before either is "
+                         "launched; late: each graph is captured right before its first replay")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="launcher / rendezvous / gather rehearsal on the CPU over gloo: no GPU work, synthetic result rows")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# Launcher: one process per GPU, started before anything in this process touches the GPU
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    n = args.gpus
+    if not args.rehearse_cpu:
+        import torch  # device_count() does not initialise the GPU
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d needs %d GPUs, %d visible\n" % (n, n, have))
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if r == 0 else subprocess.DEVNULL      # rank 0 prints the line on our stdout
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+class Ranks:
+    """Rank bookkeeping, the control-plane group (gloo: barriers, timing reductions) and,
+    when asked for, the RCCL group of the pair gather."""
+
+    def __init__(self, torch, dist, rehearse):
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.rehearse = rehearse
+        self.data_group = None
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            # Control plane on gloo: the frame workload has no data-path collective, and a process
+            # group without a GPU watchdog thread leaves HIP graph capture undisturbed.
+            # (gloo announces its connections on stdout: keep stdout for the one JSON line)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
+
+    def barrier(self):
+        if not self.rehearse:
+            self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        if not self.rehearse:
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        if self.world == 1:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    def data_plane(self, dev):
+        """The group that moves result rows: RCCL on the GPUs (created after every graph has been
+        captured), the gloo group itself in a CPU rehearsal."""
+        if self.world == 1:
+            return None
+        if self.rehearse:
+            return self.dist.group.WORLD
+        if self.data_group is None:
+            try:
+                self.data_group = self.dist.new_group(backend="nccl", device_id=dev)
+            except TypeError:
+                self.data_group = self.dist.new_group(backend="nccl")
+        return self.data_group
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
     if args.workload == "stream4k":
         return run_stream4k(args)
     if args.workload == "projection":
         return run_projection(args)
+    if args.rehearse_cpu:
+        return run_rehearsal(args)
+    return run_frames(args)
 
+
+def timed_repeats(ranks, fn, steps, repeats):
+    """`repeats` timed regions of exactly `steps` calls of fn, each between two barriers; every
+    region's time is the maximum over the ranks.  Returns the list of region times (seconds)."""
+    times = []
+    for _ in range(max(1, repeats)):
+        ranks.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        ranks.barrier()
+        times.append(time.perf_counter() - t0)
+    return ranks.max_over_ranks(times)
+
+
+def run_frames(args):
     import torch
     import torch.distributed as dist
     from slam_amd import capi, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ranks = Ranks(torch, dist, False)
+    world, rank, local_rank = ranks.world, ranks.rank, ranks.local_rank
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed.run launch with that many ranks" % args.gpus)
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     W, H, NF, B, CAP = args.width, args.height, args.nfeatures, args.batch, args.capacity
     params = capi.orb_params(nfeatures=NF)
     ex = capi.Extractor(params, W, H, max_batch=B, max_keypoints=CAP, device=local_rank)
     m = capi.Matcher(device=local_rank)
-    m.reserve(B * CAP)
+    m.reserve(B, CAP, CAP)                      # before any capture: captured calls never allocate
+    m_ratio = capi.Matcher(device=local_rank)   # the same step with the ratio test on (extra)
+    m_ratio.set_options(0.8, 0)
+    m_ratio.reserve(B, CAP, CAP)
     ws, hs, quotas, scales = ex.levels()
 
     # ---- inputs: a drifting sequence of one synthetic scene, resident in HBM ----
@@ -108,130 +255,112 @@ def main():
     d_cnt = torch.zeros(B + 1, dtype=torch.int32, device=dev)
     d_out = torch.zeros(B * CAP * DM, dtype=torch.uint8, device=dev)
     d_nout = torch.zeros(B, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    cur = {"stream": torch.cuda.current_stream().cuda_stream}
     kp_p, desc_p, cnt_p = d_kp.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr()
 
-    def step():
-        nonlocal stream
-        ex.extract_batch_async(d_img, B, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
-        m.frame_match_batch_async(B, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
-                                  cnt_p + 4, d_out, d_nout, max_dist=300.0, area=-1.0, max_level=-1,
-                                  stream=stream)
-        # the last frame of this batch is the "previous frame" of the next one
-        d_kp[:CAP * KP].copy_(d_kp[B * CAP * KP:(B + 1) * CAP * KP], non_blocking=True)
-        d_desc[:CAP * 32].copy_(d_desc[B * CAP * 32:(B + 1) * CAP * 32], non_blocking=True)
-        d_cnt[:1].copy_(d_cnt[B:B + 1], non_blocking=True)
+    def make_step(matcher, batch):
+        def step():
+            st = cur["stream"]
+            ex.extract_batch_async(d_img, batch, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, st)
+            matcher.frame_match_batch_async(batch, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
+                                            cnt_p + 4, d_out, d_nout, max_dist=300.0, area=-1.0, max_level=-1, stream=st)
+            if batch == B:
+                # the last frame of this batch is the "previous frame" of the next one
+                d_kp[:CAP * KP].copy_(d_kp[B * CAP * KP:(B + 1) * CAP * KP], non_blocking=True)
+                d_desc[:CAP * 32].copy_(d_desc[B * CAP * 32:(B + 1) * CAP * 32], non_blocking=True)
+                d_cnt[:1].copy_(d_cnt[B:B + 1], non_blocking=True)
+        return step
 
-    step()  # fills slot 0
-    for _ in range(args.warmup):
-        step()
-    # ---- eager pass with per-stage HIP events (stage times, roofline of the dominant kernel) ----
-    capi.prof_enable(args.steps * 12 + 16)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt_eager = time.perf_counter() - t0
-    stages = capi.prof_collect()
-    capi.prof_enable(0)
-    # ---- timed region: the same step captured once into a HIP graph and replayed ----
-    graph = None
-    # With a process group up (N > 1) the launches stay eager: RCCL's watchdog thread polls
-    # events, which a stream capture in global mode on another thread does not tolerate.
-    if not args.no_graph and world == 1:
+    step = make_step(m, B)
+    one_frame = make_step(m, 1)
+    step_ratio = make_step(m_ratio, B)
+
+    def capture(fn):
+        """fn's launches as a HIP graph (None if capture is not possible)."""
         try:
             torch.cuda.synchronize()
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                stream = side.cuda_stream
-                step()                      # warm-up on the capture stream
+                cur["stream"] = side.cuda_stream
+                fn()                        # warm-up on the capture stream
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                stream = side.cuda_stream
-                step()
-            stream = torch.cuda.current_stream().cuda_stream
-            for _ in range(args.warmup):
-                graph.replay()
-        except Exception as e:  # capture unsupported: report the eager timing
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                cur["stream"] = side.cuda_stream
+                fn()
+            return g
+        except Exception as e:  # capture unsupported: the eager timing is reported
             sys.stderr.write("graph capture failed (%s); timing eager launches\n" % e)
-            graph = None
-            stream = torch.cuda.current_stream().cuda_stream
-    if graph is not None:
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            graph.replay()
-        barrier()
-        dt = time.perf_counter() - t0
-    else:
-        # eager launches, timed again without the per-stage events of the pass above
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+            return None
+        finally:
+            cur["stream"] = torch.cuda.current_stream().cuda_stream
+
+    step()  # fills slot 0
+    for _ in range(args.warmup):
+        step()
+    for _ in range(3):
+        one_frame()
+    want_graph = not args.no_graph
+    graph = graph1 = None
+    if want_graph and args.graph_order == "early":
+        graph = capture(step)
+        graph1 = capture(one_frame) if rank == 0 else None
+    # ---- eager pass with per-stage HIP events (stage times, roofline of the dominant kernel) ----
+    capi.prof_enable(args.steps * 12 + 16)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ranks.barrier()
+    dt_eager = time.perf_counter() - t0
+    stages = capi.prof_collect()
+    capi.prof_enable(0)
+    # ---- timed region: the same step replayed from its HIP graph, `repeats` times `steps` steps ----
+    if want_graph and graph is None:
+        graph = capture(step)
+    timed = graph.replay if graph is not None else step
+    for _ in range(args.warmup):
+        timed()
+    times = timed_repeats(ranks, timed, args.steps, args.repeats)
+    dt = statistics.median(times)
     counts = d_cnt[1:].cpu().numpy()
     nmatch = d_nout.cpu().numpy()
     frames_per_s = world * B * args.steps / dt
 
     # ---- latency of one frame at a time (batch 1), same context ----
-    lat_ms = None
-    lat_graph_ms = None
+    lat_ms = lat_graph_ms = None
     if rank == 0:
+        reps = 50
         for _ in range(3):
-            ex.extract_batch_async(d_img, 1, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
-            m.frame_match_batch_async(1, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
-                                      cnt_p + 4, d_out, d_nout, 300.0, -1.0, -1, stream)
+            one_frame()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        reps = 50
         for _ in range(reps):
-            ex.extract_batch_async(d_img, 1, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
-            m.frame_match_batch_async(1, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
-                                      cnt_p + 4, d_out, d_nout, 300.0, -1.0, -1, stream)
+            one_frame()
             torch.cuda.synchronize()
         lat_ms = (time.perf_counter() - t1) / reps * 1e3
-        lat_graph_ms = None
-        if graph is not None:
-            try:
-                def one():
-                    ex.extract_batch_async(d_img, 1, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, stream)
-                    m.frame_match_batch_async(1, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
-                                              cnt_p + 4, d_out, d_nout, 300.0, -1.0, -1, stream)
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(torch.cuda.current_stream())
-                g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1, stream=side):
-                    stream = side.cuda_stream
-                    one()
-                stream = torch.cuda.current_stream().cuda_stream
-                for _ in range(3):
-                    g1.replay()
+        if want_graph and graph1 is None:
+            graph1 = capture(one_frame)
+        if graph1 is not None:
+            for _ in range(3):
+                graph1.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                graph1.replay()
                 torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(reps):
-                    g1.replay()
-                    torch.cuda.synchronize()
-                lat_graph_ms = (time.perf_counter() - t1) / reps * 1e3
-            except Exception as e:
-                sys.stderr.write("batch-1 graph capture failed: %s\n" % e)
-                stream = torch.cuda.current_stream().cuda_stream
+            lat_graph_ms = (time.perf_counter() - t1) / reps * 1e3
 
     # ---- roofline of the dominant kernel (algorithmic bytes per launch / event time) ----
     px = pyramid_pixels(ws, hs)
     P, P0, Ptop = sum(px), px[0], px[-1]
     K = float(counts.mean())
+    valu_peak = valu_peak_gcmp()
     alg_bytes = {
-        "resize_level (all levels)": B * ((P - Ptop) + (P - P0)),
+        "pyramid": B * ((P - Ptop) + (P - P0)),
+        "resize_level": B * ((P - Ptop) + (P - P0)),
         # the fused kernel covers two stages of the un-fused accounting:
         # FAST (P read) + 7x7 blur (P read + P written)
         "fast_nms": B * 3 * P,
@@ -243,80 +372,195 @@ def main():
         dom = max(kernel_stages, key=lambda k: kernel_stages[k][0])
         ms, calls = kernel_stages[dom]
         avg_s = ms / calls * 1e-3
-        if dom in alg_bytes:
-            ach = alg_bytes[dom] / avg_s / 1e9
+        key = dom.split(" ")[0]
+        if key in alg_bytes:
+            ach = alg_bytes[key] / avg_s / 1e9
+            pmc = pmc_counters(key, B, W, H)
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                        "traffic": pmc_traffic(dom, B, W, H),
+                        "traffic": pmc.get("traffic"),
                         "avg_launch_us": round(avg_s * 1e6, 2),
-                        "algorithmic_bytes_per_launch": int(alg_bytes[dom])}
+                        "algorithmic_bytes_per_launch": int(alg_bytes[key])}
+            if pmc.get("valu_wave_insts"):
+                # the kernel's other ceiling: VALU issue.  A wave64 VALU instruction holds one of the
+                # 1024 SIMD-32s for 2 cycles, so the launch cannot take less than insts * 2 / 1024 cycles.
+                floor_s = pmc["valu_wave_insts"] * 2.0 / N_SIMD / (CLOCK_GHZ * 1e9)
+                roofline["valu_issue"] = {"wave_insts_per_launch": int(pmc["valu_wave_insts"]),
+                                          "floor_us": round(floor_s * 1e6, 2), "frac": round(floor_s / avg_s, 4)}
         else:
             # matching is bound by integer VALU throughput (xor + popcount), not HBM or MFMA
             cmp_per_launch = float((counts.astype(np.float64) * np.roll(counts, 1)).sum())
             ach = cmp_per_launch / avg_s / 1e9
-            roofline = {"kernel": dom, "bound": "valu", "achieved": round(ach, 2), "peak": VALU_PEAK_GCMP,
-                        "unit": "Gcmp/s", "frac": round(ach / VALU_PEAK_GCMP, 5), "traffic": None,
+            roofline = {"kernel": dom, "bound": "valu", "achieved": round(ach, 2), "peak": valu_peak,
+                        "unit": "Gcmp/s", "frac": round(ach / valu_peak, 5), "traffic": None,
                         "avg_launch_us": round(avg_s * 1e6, 2)}
     stage_us = {k: round(v[0] / v[1] * 1e3, 2) for k, v in stages.items()}
 
-    # ---- keyframe-pair matching, sharded over ranks, gathered to rank 0 ----
     extra = {"launch_mode": "hip graph replay" if graph is not None else "eager",
+             "graph_order": args.graph_order if graph is not None else None,
+             "timed_regions_ms_per_step": {"median": round(dt / args.steps * 1e3, 4),
+                                           "min": round(min(times) / args.steps * 1e3, 4),
+                                           "max": round(max(times) / args.steps * 1e3, 4), "repeats": len(times)},
              "ms_per_step_eager_with_stage_events": round(dt_eager / args.steps * 1e3, 4),
              "stage_us_per_launch": stage_us, "latency_ms_batch1": None if lat_ms is None else round(lat_ms, 4),
              "latency_ms_batch1_graph": None if lat_graph_ms is None else round(lat_graph_ms, 4),
              "keypoints_per_frame": round(K, 1), "matches_per_frame": round(float(nmatch.mean()), 1)}
-    if not args.no_pairs:
-        extra["pairs"] = run_pairs(args, torch, dist, capi, synth, m, dev, rank, world, barrier)
 
-    cpu = None
+    if not args.no_extras:
+        # ---- the same step with the ratio test on (best < 0.8 x second best) ----
+        g_ratio = capture(step_ratio) if want_graph else None
+        timed_r = g_ratio.replay if g_ratio is not None else step_ratio
+        for _ in range(args.warmup):
+            timed_r()
+        tr = statistics.median(timed_repeats(ranks, timed_r, args.steps, min(3, args.repeats)))
+        extra["ratio_test_0.8"] = {"frames_per_s": round(world * B * args.steps / tr, 2),
+                                   "ms_per_step": round(tr / args.steps * 1e3, 4),
+                                   "matches_per_frame": round(float(d_nout.cpu().numpy().mean()), 1)}
+        step()  # slot 0 back to a plain step's state
+        # ---- frames arriving in pinned host memory: H2D, compute and D2H overlapped ----
+        extra["host_pipelined"] = run_host_pipelined(args, torch, ranks, ex, m, frames, dev, world)
+
+    line = {
+        "metric": "frames/s ORB extract+match @640x480 2k feats",
+        "value": round(frames_per_s, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "%dx%d synthetic frame stream, %d ORB features, 8-level 1.2 pyramid, "
+                               "brute-force Hamming vs previous frame (gates off)" % (W, H, NF),
+                   "frames_per_step_per_gpu": B, "keypoint_capacity": CAP,
+                   "parallelism": "replicas" if world > 1 else "single"},
+        "roofline": roofline, "cpu_baseline": None, "extra": extra,
+    }
+    emitted = threading.Event()
+
+    def emit():
+        if rank == 0 and not emitted.is_set():
+            emitted.set()
+            print(json.dumps(line), flush=True)
+
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(args, synth, seq)
+        line["cpu_baseline"] = cpu_baseline(args, synth, seq)
 
-    if world > 1:
-        dist.destroy_process_group()
-    if rank == 0:
-        line = {
-            "metric": "frames/s ORB extract+match @640x480 2k feats",
-            "value": round(frames_per_s, 2), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%dx%d synthetic frame stream, %d ORB features, 8-level 1.2 pyramid, "
-                                   "brute-force Hamming vs previous frame (gates off)" % (W, H, NF),
-                       "frames_per_step_per_gpu": B, "keypoint_capacity": CAP,
-                       "parallelism": "replicas" if world > 1 else "single"},
-            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
-        }
-        print(json.dumps(line), flush=True)
+    # ---- keyframe-pair matching, sharded over ranks, gathered to rank 0 ----
+    if not args.no_pairs:
+        # a rank that hangs in the exchange must not cost the whole line
+        def give_up():
+            extra["pairs"] = {"error": "not finished within %.0f s" % args.pair_deadline}
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+        guard = threading.Timer(args.pair_deadline, give_up)
+        guard.daemon = True
+        guard.start()
+        extra["pairs"] = run_pairs(args, torch, dist, capi, synth, m, dev, ranks, valu_peak)
+        guard.cancel()
+    ex.close(); m.close(); m_ratio.close()
+    ranks.close()
+    emit()
+    return 0
 
 
-def pmc_traffic(kernel, batch, width, height):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json, written by tools/summarize_profile.py from separate FETCH_SIZE
-    and WRITE_SIZE runs of this same command): 2 x FETCH_SIZE (gfx950 counts dword-per-lane
-    reads at half their bytes) + WRITE_SIZE.  None when no pass matches this batch and size."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+def run_host_pipelined(args, torch, ranks, ex, m, frames, dev, world):
+    """The frame step with inputs in pinned host memory and results copied back: two slots,
+    three streams (H2D of batch i+1, compute of batch i, D2H of batch i-1 overlap)."""
+    W, H, B, CAP = args.width, args.height, args.batch, args.capacity
+    KP, DM = 28, 16
+    u8 = torch.uint8
+    h_img = [torch.from_numpy(frames.copy()).pin_memory() for _ in range(2)]
+    d_img = [torch.empty((B, H, W), dtype=u8, device=dev) for _ in range(2)]
+    d_kp = [torch.zeros((B + 1) * CAP * KP, dtype=u8, device=dev) for _ in range(2)]
+    d_desc = [torch.zeros((B + 1) * CAP * 32, dtype=u8, device=dev) for _ in range(2)]
+    d_cnt = [torch.zeros(B + 1, dtype=torch.int32, device=dev) for _ in range(2)]
+    d_out = [torch.zeros(B * CAP * DM, dtype=u8, device=dev) for _ in range(2)]
+    d_nout = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    h_kp = [torch.empty(B * CAP * KP, dtype=u8).pin_memory() for _ in range(2)]
+    h_desc = [torch.empty(B * CAP * 32, dtype=u8).pin_memory() for _ in range(2)]
+    h_out = [torch.empty(B * CAP * DM, dtype=u8).pin_memory() for _ in range(2)]
+    h_cnt = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(2)]
+    h_nout = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(2)]
+    s_copy, s_comp, s_back = (torch.cuda.Stream(device=dev) for _ in range(3))
+    ev_in = [torch.cuda.Event() for _ in range(2)]
+    ev_done = [torch.cuda.Event() for _ in range(2)]
+    ev_out = [torch.cuda.Event() for _ in range(2)]
+    n = {"i": 0}
+
+    def submit():
+        i = n["i"]; n["i"] += 1
+        s, p = i % 2, (i - 1) % 2
+        with torch.cuda.stream(s_copy):
+            if i >= 2:
+                s_copy.wait_event(ev_done[s])       # the slot's image was last read by batch i-2
+            d_img[s].copy_(h_img[s], non_blocking=True)
+            ev_in[s].record(s_copy)
+        with torch.cuda.stream(s_comp):
+            s_comp.wait_event(ev_in[s])
+            if i >= 2:
+                s_comp.wait_event(ev_out[s])        # the slot's results of batch i-2 have left
+            if i >= 1:
+                # previous frame of this batch = last frame of the batch before (other slot)
+                d_kp[s][:CAP * KP].copy_(d_kp[p][B * CAP * KP:], non_blocking=True)
+                d_desc[s][:CAP * 32].copy_(d_desc[p][B * CAP * 32:], non_blocking=True)
+                d_cnt[s][:1].copy_(d_cnt[p][B:], non_blocking=True)
+            st = s_comp.cuda_stream
+            kp_p, desc_p, cnt_p = d_kp[s].data_ptr(), d_desc[s].data_ptr(), d_cnt[s].data_ptr()
+            ex.extract_batch_async(d_img[s], B, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, st)
+            m.frame_match_batch_async(B, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
+                                      cnt_p + 4, d_out[s], d_nout[s], max_dist=300.0, area=-1.0, max_level=-1, stream=st)
+            ev_done[s].record(s_comp)
+        with torch.cuda.stream(s_back):
+            s_back.wait_event(ev_done[s])
+            h_cnt[s].copy_(d_cnt[s][1:], non_blocking=True)
+            h_kp[s].copy_(d_kp[s][CAP * KP:], non_blocking=True)
+            h_desc[s].copy_(d_desc[s][CAP * 32:], non_blocking=True)
+            h_nout[s].copy_(d_nout[s], non_blocking=True)
+            h_out[s].copy_(d_out[s], non_blocking=True)
+            ev_out[s].record(s_back)
+
+    for _ in range(4):
+        submit()
+    t = statistics.median(timed_repeats(ranks, submit, args.steps, min(3, args.repeats)))
+    torch.cuda.synchronize()
+    return {"frames_per_s": round(world * B * args.steps / t, 2), "ms_per_step": round(t / args.steps * 1e3, 4),
+            "h2d_bytes_per_step": B * W * H, "d2h_bytes_per_step": B * CAP * (KP + 32 + DM) + 8 * B,
+            "launch_mode": "eager, 3 streams, 2 slots, pinned host buffers"}
+
+
+def pmc_counters(kernel, batch, width, height):
+    """Per-launch hardware counters of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/pmc_counters.json, written by tools/summarize_profile.py from separate FETCH_SIZE,
+    WRITE_SIZE and SQ runs of this same command): traffic = 2 x FETCH_SIZE (gfx950 counts
+    dword-per-lane reads at half their bytes) + WRITE_SIZE; valu_wave_insts = SQ_INSTS_VALU.
+    Empty when no pass matches this batch and image size."""
+    path = os.path.join(ROOT, "profiles", "pmc_counters.json")
     try:
         with open(path) as f:
             rec = json.load(f)
     except (OSError, ValueError):
-        return None
-    k = rec.get("kernels", {}).get(kernel.split(" ")[0])
+        return {}
+    k = rec.get("kernels", {}).get(kernel)
     if not k or rec.get("batch") != batch or rec.get("width") != width or rec.get("height") != height:
-        return None
-    return int(2 * k["fetch_size_kib"] * 1024 + k["write_size_kib"] * 1024)
+        return {}
+    out = {}
+    if "fetch_size_kib" in k and "write_size_kib" in k:
+        out["traffic"] = int(2 * k["fetch_size_kib"] * 1024 + k["write_size_kib"] * 1024)
+    if "sq_insts_valu" in k:
+        out["valu_wave_insts"] = float(k["sq_insts_valu"])
+    return out
 
 
-def run_pairs(args, torch, dist, capi, synth, m, dev, rank, world, barrier):
+def run_pairs(args, torch, dist, capi, synth, m, dev, ranks, valu_peak):
     """All i<j pairs of n_kf keyframes x n_per descriptors, gates off (the multi-GPU benchmark configuration)."""
     from slam_amd import pairs as pairs_mod
+    world, rank = ranks.world, ranks.rank
     n_kf, n_per = args.pair_keyframes, args.pair_desc
     desc = synth.random_descriptors(n_kf * n_per, seed=3)
     d_desc = torch.from_numpy(desc).to(dev)
     pairs = pairs_mod.all_pairs(n_kf)
     n_pairs = len(pairs)
-    pg = pairs_mod.PairGather(torch, dist, n_pairs, n_per, world, rank, dev, args.pair_chunks)
+    pg = pairs_mod.PairGather(torch, dist, n_pairs, n_per, world, rank, dev, args.pair_chunks,
+                              group=ranks.data_plane(dev))
     d_pairs = torch.from_numpy(np.ascontiguousarray(pairs[pg.lo:max(pg.hi, pg.lo + 1)])).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -325,27 +569,61 @@ def run_pairs(args, torch, dist, capi, synth, m, dev, rank, world, barrier):
                             pg.res.data_ptr() + a * n_per * 4, 300.0, -1.0, -1, stream)
 
     pg.run(compute, limit=64)  # warm-up on a few pairs per chunk, no gather
-    barrier()
+    ranks.barrier()
     t0 = time.perf_counter()
     pg.run(compute)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    ranks.barrier()
+    dt = ranks.max_over_ranks([time.perf_counter() - t0])[0]
     total_cmp = float(n_pairs) * n_per * n_per
     res = {"workload": "%d keyframes x %d descriptors, all %d pairs i<j, gates off, results gathered to rank 0"
                        % (n_kf, n_per, n_pairs),
            "gcmp_per_s": round(total_cmp / dt / 1e9, 1), "seconds": round(dt, 4), "n_gpus": world,
-           "scaling": "strong", "valu_peak_gcmp_per_gpu": VALU_PEAK_GCMP,
+           "scaling": "strong", "valu_peak_gcmp_per_gpu": valu_peak,
            "valu_nominal_gcmp_per_gpu": VALU_NOMINAL_GCMP,
-           "valu_frac": round(total_cmp / dt / 1e9 / (VALU_PEAK_GCMP * world), 4)}
+           "valu_frac": round(total_cmp / dt / 1e9 / (valu_peak * world), 4)}
     if rank == 0:
         # order-independent checksum of the gathered result, comparable across N
         out = pg.result()
         res["checksum"] = int(out.to(torch.int64).sum().item())
     return res
+
+
+def run_rehearsal(args):
+    """CPU rehearsal of everything around the kernels for N ranks: rank start-up, rendezvous,
+    barriers, the max-over-ranks reduction and the chunked gather of result rows, over gloo.
+    The rows are synthetic (a function of the global pair index); rank 0 checks the gathered
+    table and prints one JSON line marked as a rehearsal."""
+    import torch
+    import torch.distributed as dist
+    from slam_amd import pairs as pairs_mod
+    ranks = Ranks(torch, dist, True)
+    world, rank = ranks.world, ranks.rank
+    if args.gpus != world:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if os.environ.get("SLAM_AMD_BENCH_FAIL_RANK") == str(rank):   # test hook: this rank dies after the rendezvous
+        os._exit(7)
+    n_kf, n_per = min(args.pair_keyframes, 12), min(args.pair_desc, 16)
+    pairs = pairs_mod.all_pairs(n_kf)
+    dev = torch.device("cpu")
+    pg = pairs_mod.PairGather(torch, dist, len(pairs), n_per, world, rank, dev, min(args.pair_chunks, 4),
+                              group=ranks.data_plane(dev))
+
+    def rows(lo, hi):
+        g = torch.arange(lo, hi, dtype=torch.int64)[:, None] * 1000 + torch.arange(n_per, dtype=torch.int64)[None, :]
+        return g.to(torch.int32)
+
+    def compute(a, b):
+        pg.res[a:b] = rows(pg.lo + a, pg.lo + b)
+
+    times = timed_repeats(ranks, lambda: pg.run(compute), 1, 2)
+    ok = None
+    if rank == 0:
+        ok = bool(torch.equal(pg.result(), rows(0, len(pairs))))
+    ranks.close()
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "gather_ok": ok, "pairs": len(pairs),
+                          "seconds": round(statistics.median(times), 4)}), flush=True)
+    return 0 if ok in (None, True) else 1
 
 
 def run_stream4k(args):
@@ -400,6 +678,7 @@ def run_stream4k(args):
         "config": {"workload": "3840x2160 synthetic stream, 10000 ORB features, match vs previous frame, "
                                "frames in pinned host memory, 3 streams, 4 slots"},
         "data": "synthetic", "dtype": "u8"}), flush=True)
+    return 0
 
 
 def run_projection(args):
@@ -411,7 +690,7 @@ def run_projection(args):
     dev = torch.device("cuda", 0)
     ex = capi.Extractor(capi.orb_params(nfeatures=NF), W, H, max_batch=1, max_keypoints=CAP)
     m = capi.Matcher()
-    m.reserve(NQ)
+    m.reserve(1, NQ, CAP)
     seq = synth.frame_sequence(W, H, 4, seed=2)
     d_frames = [torch.from_numpy(f).cuda() for f in seq]
     d_kp = torch.zeros(CAP * 28, dtype=torch.uint8, device=dev)
@@ -457,13 +736,25 @@ def run_projection(args):
         "stage_us_per_launch": {k: round(v[0] / v[1] * 1e3, 2) for k, v in stages.items()},
         "data": "synthetic", "dtype": "u8"}), flush=True)
     ex.close(); m.close()
+    return 0
 
 
 def cpu_baseline(args, synth, seq):
-    """The CPU oracle (1 thread) on a bounded sample of the same workload."""
+    """The CPU oracle (1 thread) on a bounded sample of the same workload.  Timed on a build of the
+    oracle made for this host (gcc -O3 -march=native -ffp-contract=off, so that popcount is one
+    instruction), after checking on the first frames that it returns what the -O2 checker returns."""
     from oracle import orb_oracle as oracle
     po = oracle.params(nfeatures=args.nfeatures)
     n = args.cpu_frames
+    check = [oracle.detect_and_compute(po, seq[i % len(seq)]) for i in range(2)]
+    check_m = oracle.match_gated(check[0][1], check[0][0], check[1][1], check[1][0], 300.0, -1.0, -1)
+    build = oracle.use_native_build()
+    again = [oracle.detect_and_compute(po, seq[i % len(seq)]) for i in range(2)]
+    again_m = oracle.match_gated(again[0][1], again[0][0], again[1][1], again[1][0], 300.0, -1.0, -1)
+    same = all(a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) for a, b in zip(check, again)) and \
+        check_m.tobytes() == again_m.tobytes()
+    if not same:
+        raise RuntimeError("the %s build of the oracle disagrees with the -O2 checker" % build)
     prev = oracle.detect_and_compute(po, seq[0])
     t0 = time.perf_counter()
     for i in range(n):
@@ -473,8 +764,8 @@ def cpu_baseline(args, synth, seq):
     dt = time.perf_counter() - t0
     out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": "%d frames of the same %dx%d / %d-feature stream: extract + brute-force match vs previous "
-                     "frame, CPU oracle (oracle/orb_oracle.c, gcc -O2, 1 thread as the reference runs)" %
-                     (n, args.width, args.height, args.nfeatures)}
+                     "frame, CPU oracle (oracle/orb_oracle.c, %s, 1 thread as the reference runs; outputs "
+                     "checked equal to the -O2 build on 2 frames)" % (n, args.width, args.height, args.nfeatures, build)}
     # the same oracle with OpenMP over frames (extraction) and queries (matching)
     threads = oracle.max_threads()
     if threads > 1:
@@ -492,7 +783,7 @@ def cpu_baseline(args, synth, seq):
 
 if __name__ == "__main__":
     try:
-        main()
+        code = main()
     except BaseException as e:
         if isinstance(e, SystemExit) and not e.code:
             raise
@@ -503,3 +794,5 @@ if __name__ == "__main__":
         sys.stderr.flush()
         sys.stdout.flush()
         os._exit(1)
+    sys.stdout.flush()
+    sys.exit(code or 0)

@@ -112,6 +112,11 @@ int slam_amd_extractor_levels(const slam_amd_extractor* ex, int* nlevels, int* w
 int slam_amd_extract(slam_amd_extractor* ex, const uint8_t* gray, int width, int height,
                      int stride, slam_amd_keypoint* kp_out, uint8_t* desc_out,
                      int capacity, int* n_out);
+/* Host, blocking.  Copies out the keypoints and descriptors of the last slam_amd_extract
+ * call of this context again (they stay on the device until the next call): the way to
+ * complete a call that ended in SLAM_AMD_ERR_CAPACITY without extracting a second time. */
+int slam_amd_extract_fetch(slam_amd_extractor* ex, slam_amd_keypoint* kp_out, uint8_t* desc_out,
+                           int capacity, int* n_out);
 
 /* Device, asynchronous, batched.  d_images: `batch` frames, frame b starts at
  * d_images + b*frame_pitch, rows `row_stride` bytes apart.  Outputs are
@@ -149,9 +154,17 @@ int slam_amd_extractor_debug_set_row_list_capacity(slam_amd_extractor* ex, int e
 
 int slam_amd_matcher_create(int device, slam_amd_matcher** out);
 int slam_amd_matcher_destroy(slam_amd_matcher* m);
-/* Sizes the matcher's device scratch (4 bytes per query row over all problems
- * of a call) so that later _async calls of at most that size allocate nothing. */
-int slam_amd_matcher_reserve(slam_amd_matcher* m, size_t query_rows);
+/* Sizes the matcher's device scratch for calls of at most `batch` problems of at most
+ * `query_rows` x `train_rows` rows each (train_rows may be 0 when the window-gated,
+ * cell-sorted path will not be used): 4 bytes per query row, 128 more while the ratio
+ * option is set, 44 per row of both sets for the cell-sorted path.  Later _async calls
+ * within these sizes allocate nothing.
+ * Rule for HIP graphs: an _async call issued while its stream is capturing never
+ * allocates -- if the scratch is too small it returns SLAM_AMD_ERR_CAPACITY -- and once a
+ * call has been captured the scratch never moves again (a later call that would need more
+ * returns SLAM_AMD_ERR_CAPACITY too, because the instantiated graph holds the old
+ * address).  So: reserve (and set the options) first, then capture. */
+int slam_amd_matcher_reserve(slam_amd_matcher* m, int batch, int query_rows, int train_rows);
 
 /* Two post-filters the reference does not have (it calls radiusMatch and keeps the
  * nearest gated row, src/frame/matcher.cpp:131-161); both are off after create and

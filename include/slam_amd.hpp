@@ -112,8 +112,15 @@ public:
                                             reinterpret_cast<slam_amd_keypoint*>(keypoints.data()),
                                             descriptors.bytes.data(), capacity, &n);
             if (rc == SLAM_AMD_ERR_CAPACITY && n > capacity && n <= max_keypoints_) {
-                capacity = n;  // score ties pushed the count above the guess: retry with the exact size
-                continue;
+                // score ties pushed the count above the guess; the results are still on the
+                // device, so they are fetched into buffers of the exact size -- no second extraction
+                capacity = n;
+                keypoints.resize(static_cast<size_t>(capacity));
+                descriptors.bytes.resize(static_cast<size_t>(capacity) * 32);
+                check(slam_amd_extract_fetch(ex_, reinterpret_cast<slam_amd_keypoint*>(keypoints.data()),
+                                             descriptors.bytes.data(), capacity, &n));
+                descriptors.rows = n;
+                return;
             }
             if (rc == SLAM_AMD_ERR_CAPACITY && n > max_keypoints_) {
                 // more ties than the context was sized for: rebuild it larger, once

@@ -61,6 +61,32 @@ def lib():
     return _lib
 
 
+def use_native_build():
+    """Switches this module to a build of the same source made for the CPU it runs on
+    (gcc -O3 -march=native -ffp-contract=off, in a temporary directory), for timing the CPU
+    baseline.  Returns a description of the build in use; on any failure the -O2 library
+    stays in use."""
+    global _lib
+    import tempfile
+    flags = ["-O3", "-march=native", "-std=c99", "-fPIC", "-ffp-contract=off", "-fopenmp"]
+    try:
+        out = os.path.join(tempfile.mkdtemp(prefix="orb_oracle_native_"), "liborb_oracle_native.so")
+        subprocess.check_call(["gcc"] + flags + ["-shared", "-o", out, os.path.join(_HERE, "orb_oracle.c"), "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        new = C.CDLL(out)
+    except (OSError, subprocess.CalledProcessError):
+        lib()
+        return "gcc -O2 (native build failed)"
+    _lib = None
+    lib()                      # sets the restype / argtypes on the default library object ...
+    new.orc_fast_atan2.restype = C.c_float
+    new.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+    new.orc_level_scale.restype = C.c_float
+    new.orc_level_scale.argtypes = [C.POINTER(Params), C.c_int]
+    _lib = new                 # ... and the native one takes its place
+    return "gcc " + " ".join(flags[:2] + flags[4:5])
+
+
 def params(nfeatures=1000, scale_factor=1.2, nlevels=8, edge_threshold=31, fast_threshold=20,
            first_level=0, wta_k=2, score_type=1, patch_size=31):
     return Params(nfeatures, scale_factor, nlevels, edge_threshold, first_level, wta_k,

@@ -27,7 +27,7 @@ EXPORTS = [
     "slam_amd_version", "slam_amd_status_string", "slam_amd_last_error", "slam_amd_device_count",
     "slam_amd_default_orb_params",
     "slam_amd_extractor_create", "slam_amd_extractor_destroy", "slam_amd_extractor_levels", "slam_amd_extractor_set_grid",
-    "slam_amd_extract", "slam_amd_extract_batch_async", "slam_amd_extractor_debug_level",
+    "slam_amd_extract", "slam_amd_extract_fetch", "slam_amd_extract_batch_async", "slam_amd_extractor_debug_level",
     "slam_amd_extractor_debug_blurred_level", "slam_amd_extractor_debug_set_row_list_capacity",
     "slam_amd_matcher_create", "slam_amd_matcher_destroy", "slam_amd_matcher_reserve",
     "slam_amd_matcher_set_options", "slam_amd_matcher_debug_set_window_mode",
@@ -76,7 +76,8 @@ def lib():
         l.slam_amd_sincos_f32.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.slam_amd_sincos_f32.restype = None
         l.slam_amd_default_orb_params.restype = None
-        l.slam_amd_matcher_reserve.argtypes = [C.c_void_p, C.c_size_t]
+        l.slam_amd_matcher_reserve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        l.slam_amd_extract_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         l.slam_amd_matcher_set_options.argtypes = [C.c_void_p, C.c_float, C.c_int]
         l.slam_amd_matcher_debug_set_window_mode.argtypes = [C.c_void_p, C.c_int]
         l.slam_amd_extract_batch_async.argtypes = [
@@ -234,6 +235,14 @@ class Extractor:
                                       cap, C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def extract_fetch(self, capacity):
+        """Results of the last extract() call again (e.g. after it ended in ERR_CAPACITY)."""
+        kps = np.zeros(max(capacity, 1), KEYPOINT_DTYPE)
+        desc = np.zeros((max(capacity, 1), 32), np.uint8)
+        n = C.c_int(0)
+        check(lib().slam_amd_extract_fetch(self._h, _ptr(kps), _ptr(desc), capacity, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
     def extract_batch_async(self, d_images, batch, frame_pitch, row_stride, d_kp, d_desc, d_count,
                             capacity, stream=0):
         check(lib().slam_amd_extract_batch_async(self._h, _ptr(d_images), batch, frame_pitch, row_stride,
@@ -312,8 +321,10 @@ class Matcher:
         except Exception:
             pass
 
-    def reserve(self, rows):
-        check(lib().slam_amd_matcher_reserve(self._h, rows))
+    def reserve(self, batch, query_rows, train_rows=0):
+        """Size the device scratch for calls of at most `batch` problems of query_rows x train_rows rows
+        (train_rows only matters for the cell-sorted windowed path).  Do this before capturing a HIP graph."""
+        check(lib().slam_amd_matcher_reserve(self._h, int(batch), int(query_rows), int(train_rows)))
 
     def debug_set_window_mode(self, mode):
         check(lib().slam_amd_matcher_debug_set_window_mode(self._h, mode))

@@ -101,6 +101,7 @@ struct slam_amd_extractor {
     // host-call staging
     DevBuf h_img, h_kp, h_desc, h_count;
     int h_img_pitch = 0;
+    int h_last_n = -1;                 // keypoints of the last host call still in h_kp / h_desc (-1: none)
     hipStream_t stream = nullptr;
     // geometry of the last batch (debug accessor)
     const uint8_t* last_img0 = nullptr;
@@ -263,10 +264,18 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
     if ((rc = ex->smap.reserve(B * g.frame_bytes))) return fail(rc);
     if ((rc = ex->blur.reserve(B * g.frame_bytes))) return fail(rc);
     // histogram and row fill counters share one allocation: one memset clears both
-    if ((rc = ex->hist.reserve(B * ((size_t)g.nlevels * 256 + g.total_rows) * sizeof(unsigned)))) return fail(rc);
+    // (padded to 256 bytes: the per-call fill is rounded up to whole 256-byte blocks)
+    if ((rc = ex->hist.reserve(((B * ((size_t)g.nlevels * 256 + g.total_rows) * sizeof(unsigned)) + 255) & ~(size_t)255))) return fail(rc);
     if ((rc = ex->rowlist.reserve(B * (size_t)g.total_rows * kRowListCap * sizeof(uint32_t)))) return fail(rc);
     if ((rc = ex->sel.reserve(B * sizeof(FrameSelect)))) return fail(rc);
     if ((rc = ex->kpxy.reserve(B * (size_t)max_keypoints * sizeof(uint32_t)))) return fail(rc);
+    // packed positions start out as zeros: a slot that was never written decodes to (0, 0, level 0),
+    // which the describe kernel rejects, instead of an arbitrary address
+    if (hipMemset(ex->kpxy.p, 0, ex->kpxy.cap) != hipSuccess || hipMemset(ex->sel.p, 0, ex->sel.cap) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipMemset of the selection buffers failed");
+        return fail(SLAM_AMD_ERR_HIP);
+    }
     hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__));
     *out = ex;
@@ -319,7 +328,8 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
 
     {
         ProfScope ps(kStageMemset, st);
-        SA_HIP(hipMemsetAsync(ex->hist.p, 0, (size_t)batch * ((size_t)g.nlevels * 256 + g.total_rows) * sizeof(unsigned), st));
+        const size_t bytes = (size_t)batch * ((size_t)g.nlevels * 256 + g.total_rows) * sizeof(unsigned);
+        SA_HIP(hipMemsetAsync(ex->hist.p, 0, (bytes + 255) & ~(size_t)255, st));
     }
     int rc;
     prof_mark(kStageResize, true, st);
@@ -377,6 +387,7 @@ extern "C" int slam_amd_extract(slam_amd_extractor* ex, const uint8_t* gray, int
     if ((rc = ex->h_kp.reserve((size_t)cap * sizeof(slam_amd_keypoint)))) return rc;
     if ((rc = ex->h_desc.reserve((size_t)cap * 32))) return rc;
     if ((rc = ex->h_count.reserve(sizeof(int32_t)))) return rc;
+    ex->h_last_n = -1;
     SA_HIP(hipMemcpy2DAsync(ex->h_img.p, ex->h_img_pitch, gray, stride, width, height,
                             hipMemcpyHostToDevice, ex->stream));
     rc = slam_amd_extract_batch_async(ex, ex->h_img.as<uint8_t>(), 1, 0, ex->h_img_pitch,
@@ -388,7 +399,19 @@ extern "C" int slam_amd_extract(slam_amd_extractor* ex, const uint8_t* gray, int
     SA_HIP(hipStreamSynchronize(ex->stream));
     *n_out = n;
     if (n > cap) SA_FAIL(SLAM_AMD_ERR_CAPACITY, "more keypoints than the extractor's max_keypoints");
+    ex->h_last_n = n;
+    return slam_amd_extract_fetch(ex, kp_out, desc_out, capacity, n_out);
+}
+
+extern "C" int slam_amd_extract_fetch(slam_amd_extractor* ex, slam_amd_keypoint* kp_out, uint8_t* desc_out,
+                                      int capacity, int* n_out) {
+    if (!ex || !n_out) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
+    if (ex->h_last_n < 0) SA_FAIL(SLAM_AMD_ERR_ARG, "no complete slam_amd_extract result is held by this context");
+    const int n = ex->h_last_n;
+    *n_out = n;
+    if (capacity < 0 || (capacity > 0 && (!kp_out || !desc_out))) SA_FAIL(SLAM_AMD_ERR_ARG, "null output");
     if (n > capacity) SA_FAIL(SLAM_AMD_ERR_CAPACITY, "more keypoints than the caller's capacity");
+    SA_HIP(hipSetDevice(ex->device));
     if (n > 0) {
         SA_HIP(hipMemcpyAsync(kp_out, ex->h_kp.p, (size_t)n * sizeof(slam_amd_keypoint), hipMemcpyDeviceToHost, ex->stream));
         SA_HIP(hipMemcpyAsync(desc_out, ex->h_desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, ex->stream));
@@ -453,6 +476,7 @@ struct slam_amd_matcher {
     DevBuf best;                       // running keys of the async calls
     DevBuf part;                       // per-split (best, second) keys when the ratio test is on
     DevBuf sorted;                     // both sets in grid-cell order for windowed matching
+    bool baked = false;                // an _async call ran under stream capture: scratch pointers live in a graph
     int window_mode = 0;               // 0: choose by size, 1: always the full sweep, 2: always cell-sorted
     float ratio = 0.f;                 // options beyond the reference, both off by default
     int histo_length = 0;
@@ -487,14 +511,60 @@ extern "C" int slam_amd_matcher_destroy(slam_amd_matcher* m) {
     return SLAM_AMD_OK;
 }
 
-extern "C" int slam_amd_matcher_reserve(slam_amd_matcher* m, size_t query_rows) {
-    if (!m) SA_FAIL(SLAM_AMD_ERR_ARG, "matcher is null");
-    SA_HIP(hipSetDevice(m->device));
-    if (m->ratio > 0.f) {
-        int rc = m->part.reserve(query_rows * kMaxSecondSplits * sizeof(uint2));
-        if (rc) return rc;
+// Device scratch of the matcher grows on demand, except where growing would break a
+// captured graph: hipFree / hipMalloc are illegal while the stream is capturing, and a
+// graph instantiated earlier keeps the old pointer.  Fill bytes are rounded up to 256 so
+// that every hipMemsetAsync covers whole 16-byte multiples.
+static size_t fill_bytes(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+static bool stream_capturing(hipStream_t st) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &status) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return status == hipStreamCaptureStatusActive;
+}
+
+static int grow_scratch(slam_amd_matcher* m, DevBuf& b, size_t bytes, bool capturing) {
+    if (bytes <= b.cap) return SLAM_AMD_OK;
+    if (capturing || m->baked)
+        SA_FAIL(SLAM_AMD_ERR_CAPACITY, "matcher scratch too small and a captured graph holds (or is recording) its "
+                                       "address: call slam_amd_matcher_reserve with the largest sizes before capturing");
+    return b.reserve(bytes);
+}
+
+// Byte layout of the cell-sorted copies of both sets (set 0 = queries, 1 = train): per row
+// descriptors (32 B), position (8 B), index word (4 B); a box (16 B) per 64 rows.
+struct SortedLayout {
+    int scap[2];
+    size_t o_desc[2], o_xy[2], o_idx[2], o_box[2], total;
+};
+static SortedLayout sorted_layout(int batch, int nq, int n2) {
+    SortedLayout L;
+    size_t off = 0;
+    for (int s = 0; s < 2; s++) {
+        const int bound = s == 0 ? nq : n2;
+        L.scap[s] = div_up(std::max(bound, 1), 64) * 64;
+        const size_t r = (size_t)batch * L.scap[s];
+        L.o_desc[s] = off; off += r * 32;
+        L.o_xy[s] = off; off += r * 8;
+        L.o_idx[s] = off; off += r * 4;
+        L.o_box[s] = off; off += (r / 64) * 16;
+        off = (off + 255) & ~(size_t)255;
     }
-    return m->best.reserve(query_rows * sizeof(unsigned));
+    L.total = off;
+    return L;
+}
+
+extern "C" int slam_amd_matcher_reserve(slam_amd_matcher* m, int batch, int query_rows, int train_rows) {
+    if (!m) SA_FAIL(SLAM_AMD_ERR_ARG, "matcher is null");
+    if (batch <= 0 || query_rows < 0 || train_rows < 0) SA_FAIL(SLAM_AMD_ERR_ARG, "bad size");
+    SA_HIP(hipSetDevice(m->device));
+    const size_t rows = std::max((size_t)batch * (size_t)query_rows, (size_t)1);
+    int rc;
+    if ((rc = grow_scratch(m, m->best, fill_bytes(rows * sizeof(unsigned)), false))) return rc;
+    if (m->ratio > 0.f && (rc = grow_scratch(m, m->part, fill_bytes(rows * kMaxSecondSplits * sizeof(uint2)), false))) return rc;
+    if (train_rows > 0 && query_rows > 0 &&
+        (rc = grow_scratch(m, m->sorted, sorted_layout(batch, query_rows, train_rows).total, false))) return rc;
+    return SLAM_AMD_OK;
 }
 
 extern "C" int slam_amd_matcher_debug_set_window_mode(slam_amd_matcher* m, int mode) {
@@ -548,17 +618,21 @@ static int match_common(slam_amd_matcher* m, int batch,
     MatchPlan plan = plan_match(batch, nq, n2, m->n_cu, second);
     if (windowed) plan.splits = window_splits(batch, nq, n2, m->n_cu);
     int rc;
-    if (second) {
-        // every (query, split) cell is written by the kernel only where the split holds
-        // train rows, so the planes start out as "no match"
-        const size_t bytes = rows * plan.splits * sizeof(uint2);
-        if ((rc = m->part.reserve(bytes))) return rc;
+    const bool capturing = stream_capturing(st);
+    unsigned* best_p;
+    uint2* part_p;
+    {
+        if (second) { if ((rc = grow_scratch(m, m->part, fill_bytes(rows * plan.splits * sizeof(uint2)), capturing))) return rc; }
+        else if ((rc = grow_scratch(m, m->best, fill_bytes(rows * sizeof(unsigned)), capturing))) return rc;
+        best_p = m->best.as<unsigned>();
+        part_p = m->part.as<uint2>();
+    }
+    {
+        // every (query, split) cell of the planes is written by the kernel only where the split
+        // holds train rows, and the single-plane keys are merged by atomicMin: both start as "no match"
+        const size_t bytes = second ? fill_bytes(rows * plan.splits * sizeof(uint2)) : fill_bytes(rows * sizeof(unsigned));
         ProfScope ps(kStageMemset, st);
-        SA_HIP(hipMemsetAsync(m->part.p, 0xff, bytes, st));
-    } else {
-        if ((rc = m->best.reserve(rows * sizeof(unsigned)))) return rc;
-        ProfScope ps(kStageMemset, st);
-        SA_HIP(hipMemsetAsync(m->best.p, 0xff, rows * sizeof(unsigned), st));
+        SA_HIP(hipMemsetAsync(second ? static_cast<void*>(part_p) : static_cast<void*>(best_p), 0xff, bytes, st));
     }
     const int dmax = dmax_of(max_dist);
     if (windowed) {
@@ -567,21 +641,11 @@ static int match_common(slam_amd_matcher* m, int batch,
         sa_.qdesc = d1; sa_.qkp = k1; sa_.d_n1 = d_n1; sa_.n1 = n1; sa_.cap1 = cap1;
         sa_.tdesc = d2; sa_.tkp = k2; sa_.d_n2 = d_n2; sa_.n2 = n2; sa_.cap2 = cap2;
         sa_.ids = ids; sa_.n_ids = n_ids; sa_.q_xy = q_xy; sa_.area = area; sa_.max_level = max_level;
-        // one allocation: per set descriptors (32 B), positions (8 B), indices (4 B) per row
-        // and a box (16 B) per 64 rows
-        size_t off = 0;
-        size_t o_desc[2], o_xy[2], o_idx[2], o_box[2];
-        for (int s = 0; s < 2; s++) {
-            const int bound = s == 0 ? nq : n2;
-            sa_.scap[s] = div_up(bound, 64) * 64;
-            const size_t r = (size_t)batch * sa_.scap[s];
-            o_desc[s] = off; off += r * 32;
-            o_xy[s] = off; off += r * 8;
-            o_idx[s] = off; off += r * 4;
-            o_box[s] = off; off += (r / 64) * 16;
-            off = (off + 255) & ~(size_t)255;
-        }
-        if ((rc = m->sorted.reserve(off))) return rc;
+        const SortedLayout lay = sorted_layout(batch, nq, n2);
+        const size_t* o_desc = lay.o_desc; const size_t* o_xy = lay.o_xy;
+        const size_t* o_idx = lay.o_idx; const size_t* o_box = lay.o_box;
+        sa_.scap[0] = lay.scap[0]; sa_.scap[1] = lay.scap[1];
+        if ((rc = grow_scratch(m, m->sorted, lay.total, capturing))) return rc;
         uint8_t* basep = m->sorted.as<uint8_t>();
         WindowMatchArgs w;
         memset(&w, 0, sizeof w);
@@ -595,8 +659,8 @@ static int match_common(slam_amd_matcher* m, int batch,
         w.tile_box = sa_.tile_box[1];
         w.d_n1 = d_n1; w.n1 = n1; w.d_n2 = d_n2; w.n2 = n2; w.has_ids = ids != nullptr; w.n_ids = n_ids;
         w.cap1 = cap1; w.area = area; w.max_level = max_level; w.batch = batch;
-        w.best = m->best.as<unsigned>();
-        w.part = second ? m->part.as<uint2>() : nullptr;
+        w.best = best_p;
+        w.part = second ? part_p : nullptr;
         w.part_pitch = rows;
         w.splits = plan.splits;
         { ProfScope ps(kStageSpatialSort, st); if ((rc = launch_spatial_sort(sa_, batch, nq, n2, st))) return rc; }
@@ -608,18 +672,19 @@ static int match_common(slam_amd_matcher* m, int batch,
         a.tdesc = d2; a.tkp = k2; a.d_n2 = d_n2; a.n2 = n2;
         a.ids = ids; a.n_ids = n_ids; a.q_xy = q_xy; a.cap1 = cap1; a.cap2 = cap2;
         a.area = area; a.max_level = max_level; a.dmax = dmax;
-        a.best = m->best.as<unsigned>();
-        a.part = second ? m->part.as<uint2>() : nullptr;
+        a.best = best_p;
+        a.part = second ? part_p : nullptr;
         a.part_pitch = rows;
         ProfScope ps(kStageMatch, st);
         if ((rc = launch_match(a, plan, batch, st))) return rc;
     }
     FinalizeArgs f;
     memset(&f, 0, sizeof f);
-    f.best = m->best.as<unsigned>(); f.d_n1 = d_n1; f.n1 = n1; f.ids = ids; f.n_ids = n_ids;
+    f.best = best_p; f.d_n1 = d_n1; f.n1 = n1; f.ids = ids; f.n_ids = n_ids;
     f.cap1 = cap1; f.dmax = dmax; f.out = d_out; f.n_out = d_n_out;
-    f.part = second ? m->part.as<uint2>() : nullptr; f.part_pitch = rows; f.splits = plan.splits;
+    f.part = second ? part_p : nullptr; f.part_pitch = rows; f.splits = plan.splits;
     f.ratio = m->ratio; f.histo_length = m->histo_length; f.qkp = k1; f.tkp = k2; f.cap2 = cap2;
+    if (capturing) m->baked = true;
     ProfScope ps(kStageFinalize, st);
     return launch_finalize(f, batch, st);
 }

@@ -651,7 +651,7 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs 
         base += pass_total;
         if (cnt == 0) continue;
         auto emit = [&](unsigned x, unsigned sc) {
-            if (pos < a.capacity) {
+            if ((unsigned)pos < (unsigned)a.capacity) {
                 slam_amd_keypoint q;
                 q.x = (float)x;
                 q.y = (float)y;
@@ -806,6 +806,11 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
     const int x = (int)(xy & 0x3fffu), y = (int)((xy >> 14) & 0x3fffu);
     const int l = (int)(xy >> 28);
     const LevelGeom& L = a.g.lv[l];
+    // Both patches must lie inside the level.  The selection kernel only emits positions at least
+    // `edge` (>= 31) pixels from the border, so this rejects nothing it wrote; it keeps a record that
+    // was never written (zeros) or a count that ran ahead of the records from becoming a wild read.
+    // (24 = patch radius 18 + the up to 3 + 3 bytes the aligned dword loads reach further.)
+    if (l >= a.g.nlevels || x < 24 || y < 24 || x >= L.w - 24 || y >= L.h - 24) return;
     const uint8_t* img;
     int pitch;
     bool aligned = true;

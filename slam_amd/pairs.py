@@ -32,10 +32,11 @@ def chunk_rows(per, chunks, c):
 class PairGather:
     """Per-rank result buffer [per, n_per] int32 plus the chunked gather to rank 0."""
 
-    def __init__(self, torch, dist, n_pairs, n_per, world, rank, device, chunks, collective=None):
+    def __init__(self, torch, dist, n_pairs, n_per, world, rank, device, chunks, collective=None, group=None):
         """collective: run the gather even for world == 1 (a one-rank process group, to
-        exercise the exchange on a single GPU); default: only when world > 1."""
-        self.torch, self.dist = torch, dist
+        exercise the exchange on a single GPU); default: only when world > 1.
+        group: the process group that carries the gather (default: the default group)."""
+        self.torch, self.dist, self.group = torch, dist, group
         self.world, self.rank, self.chunks = world, rank, max(1, chunks)
         self.collective = (world > 1) if collective is None else bool(collective)
         self.lo, self.hi, self.per = shard(n_pairs, world, rank)
@@ -70,9 +71,9 @@ class PairGather:
                     ev.record()
                     with torch.cuda.stream(self.comm):
                         self.comm.wait_event(ev)
-                        handles.append(dist.gather(src, outs, dst=0, async_op=True))
+                        handles.append(dist.gather(src, outs, dst=0, group=self.group, async_op=True))
                 else:
-                    handles.append(dist.gather(src, outs, dst=0, async_op=True))
+                    handles.append(dist.gather(src, outs, dst=0, group=self.group, async_op=True))
         for h in handles:
             h.wait()
         if self.comm is not None:

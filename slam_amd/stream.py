@@ -26,7 +26,7 @@ class FramePipeline:
         self.dev = dev
         self.ex = capi.Extractor(params, width, height, max_batch=1, max_keypoints=capacity, device=device)
         self.m = capi.Matcher(device=device)
-        self.m.reserve(capacity)
+        self.m.reserve(1, capacity, capacity)
         self.s_copy = torch.cuda.Stream(device=dev)
         self.s_comp = torch.cuda.Stream(device=dev)
         self.s_back = torch.cuda.Stream(device=dev)

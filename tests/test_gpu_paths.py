@@ -223,7 +223,7 @@ def test_frame_match_async_and_batch(oracle, capi):
     st = torch.cuda.current_stream().cuda_stream
     B, CAP = 4, 512
     m = capi.Matcher()
-    m.reserve(B * CAP)
+    m.reserve(B, CAP, CAP)
     n1 = [300, 512, 0, 77]; n2 = [410, 1, 100, 512]
     sets = [_sets(CAP, CAP, 50 + b) for b in range(B)]
     D1 = torch.from_numpy(np.concatenate([s[0] for s in sets])).cuda()
@@ -246,7 +246,7 @@ def test_frame_match_async_and_batch(oracle, capi):
     m.debug_set_window_mode(2)
     # the two optional post-filters on the batched device path
     m.set_options(0.9, 30)
-    m.reserve(B * CAP)
+    m.reserve(B, CAP, CAP)
     m.frame_match_batch_async(B, D1, K1, CAP, N1, D2, K2, CAP, N2, out, nout, 300.0, 80.0, 4, st)
     torch.cuda.synchronize()
     res = out.cpu().numpy().view(capi.DMATCH_DTYPE)

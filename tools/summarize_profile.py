@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Condenses a tools/profile_round.sh output directory into one text summary for profiles/."""
+"""Condenses a tools/profile_round.sh output directory into one text summary for profiles/.
+Usage: tools/summarize_profile.py gpurun_out/prof_<tag> [profiles/pmc_counters.json] > profiles/<tag>_rocprofv3_summary.txt"""
 import collections
 import csv
 import glob
@@ -60,16 +61,19 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
 if len(sys.argv) > 2:
     rec = {"kernels": {}}
     vals = collections.defaultdict(dict)
-    for name, key in (("pmc_fetch", "fetch_size_kib"), ("pmc_write", "write_size_kib")):
+    for name, only in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_sq", None)):
         files = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))
         if not files:
             continue
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(files[0])):
-            per[kernel_short(r["Kernel_Name"])].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
-        for k, v in per.items():
+            if only and r["Counter_Name"] != only:
+                continue
+            per[(kernel_short(r["Kernel_Name"]), r["Counter_Name"])].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+        for (k, counter), v in per.items():
             if k.startswith("at::") or k.startswith("__amd") or not k:
                 continue
+            key = {"FETCH_SIZE": "fetch_size_kib", "WRITE_SIZE": "write_size_kib"}.get(counter, counter.lower())
             gmax = max(g for g, _ in v)
             sel = [x for g, x in v if g == gmax]
             short = k.replace("_kernel", "").split("<")[0]
@@ -85,7 +89,7 @@ if len(sys.argv) > 2:
         rec["width"], rec["height"] = int(wl[0]), int(wl[1])
     except Exception:
         pass
-    rec["source"] = "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs of bench.py; per launch, largest grid"
+    rec["source"] = "rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_*, separate runs of bench.py; per launch, largest grid"
     json.dump(rec, open(sys.argv[2], "w"), indent=1)
 for j in ("trace_bench.json",):
     p = os.path.join(src, j)
