@@ -220,6 +220,26 @@ int slam_amd_frame_match_async(slam_amd_matcher* m,
                                float max_dist, float area, int max_level,
                                slam_amd_dmatch* d_out, int32_t* d_n_out, void* stream);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory -- code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc: the same
+ * call as slam_amd_frame_match_async (same arguments, same results), but its device scratch
+ * -- the running best keys, and the (best, second) planes while the ratio option is set --
+ * is a fixed array inside the library's code object (4.1 MiB per GPU, held until the process
+ * ends) instead of buffers the matcher allocates.  It calls no hipMalloc / hipFree, and always
+ * uses the full sweep (never the cell-sorted window path, which needs reordered copies).
+ * At most SLAM_AMD_NOALLOC_MAX_QUERIES query rows (max(n1, n_ids)); more is
+ * SLAM_AMD_ERR_CAPACITY.  All calls on one GPU share that GPU's array: calls that overlap in
+ * time on one GPU (different streams, different matchers) race; serialise them. */
+#define SLAM_AMD_NOALLOC_MAX_QUERIES 32768
+int slam_amd_frame_match_noalloc_async(slam_amd_matcher* m,
+                                       const uint8_t* d_desc1, const slam_amd_keypoint* d_kp1, int n1,
+                                       const int32_t* d_n1,
+                                       const uint8_t* d_desc2, const slam_amd_keypoint* d_kp2, int n2,
+                                       const int32_t* d_n2,
+                                       const int32_t* d_ids, int n_ids, const float* d_q_xy,
+                                       float max_dist, float area, int max_level,
+                                       slam_amd_dmatch* d_out, int32_t* d_n_out, void* stream);
+
 /* Batched matching of `batch` independent (set 1, set 2) problems of equal
  * capacity in one launch: problem b uses rows [b*cap1, b*cap1+n1[b]) of set 1
  * and [b*cap2, b*cap2+n2[b]) of set 2 (counts on the device).  Output

@@ -31,7 +31,8 @@ EXPORTS = [
     "slam_amd_extractor_debug_blurred_level", "slam_amd_extractor_debug_set_row_list_capacity",
     "slam_amd_matcher_create", "slam_amd_matcher_destroy", "slam_amd_matcher_reserve",
     "slam_amd_matcher_set_options", "slam_amd_matcher_debug_set_window_mode",
-    "slam_amd_frame_match", "slam_amd_frame_match_async", "slam_amd_frame_match_batch_async",
+    "slam_amd_frame_match", "slam_amd_frame_match_async", "slam_amd_frame_match_noalloc_async",
+    "slam_amd_frame_match_batch_async",
     "slam_amd_match_pairs_async",
     "slam_amd_project_points", "slam_amd_project_points_async", "slam_amd_duplicate_pairs",
     "slam_amd_outlier_flags",
@@ -87,6 +88,7 @@ def lib():
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
             C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int,
             C.c_void_p, C.c_void_p, C.c_void_p]
+        l.slam_amd_frame_match_noalloc_async.argtypes = l.slam_amd_frame_match_async.argtypes
         l.slam_amd_frame_match_batch_async.argtypes = [
             C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
             C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -357,6 +359,16 @@ class Matcher:
                                                 _ptr(d_ids), n_ids, _ptr(d_q_xy), max_dist, area,
                                                 int(max_level), _ptr(d_out), _ptr(d_n_out),
                                                 C.c_void_p(stream)))
+
+    def frame_match_noalloc_async(self, d_desc1, d_kp1, n1, d_n1, d_desc2, d_kp2, n2, d_n2, d_out, d_n_out,
+                                  d_ids=None, n_ids=0, d_q_xy=None, max_dist=300.0, area=-1.0, max_level=4,
+                                  stream=0):
+        """frame_match_async on the library's static device scratch: allocates nothing."""
+        check(lib().slam_amd_frame_match_noalloc_async(self._h, _ptr(d_desc1), _ptr(d_kp1), n1, _ptr(d_n1),
+                                                        _ptr(d_desc2), _ptr(d_kp2), n2, _ptr(d_n2),
+                                                        _ptr(d_ids), n_ids, _ptr(d_q_xy), max_dist, area,
+                                                        int(max_level), _ptr(d_out), _ptr(d_n_out),
+                                                        C.c_void_p(stream)))
 
     def frame_match_batch_async(self, batch, d_desc1, d_kp1, cap1, d_n1, d_desc2, d_kp2, cap2, d_n2,
                                 d_out, d_n_out, max_dist=300.0, area=-1.0, max_level=4, stream=0):

@@ -477,11 +477,20 @@ struct slam_amd_matcher {
     DevBuf part;                       // per-split (best, second) keys when the ratio test is on
     DevBuf sorted;                     // both sets in grid-cell order for windowed matching
     bool baked = false;                // an _async call ran under stream capture: scratch pointers live in a graph
+    unsigned char* static_scratch = nullptr;  // this device's copy of the file-scope scratch array (no-alloc entry point)
     int window_mode = 0;               // 0: choose by size, 1: always the full sweep, 2: always cell-sorted
     float ratio = 0.f;                 // options beyond the reference, both off by default
     int histo_length = 0;
     DevBuf h_d1, h_k1, h_d2, h_k2, h_ids, h_xy, h_out, h_n, h_aux;  // host-call staging
 };
+
+// Scratch of slam_amd_frame_match_noalloc_async: running keys of up to kStaticRows queries, then
+// the (best, second) planes of the ratio option.  One copy per GPU, held until the process ends;
+// host code reaches it only through the address hipGetSymbolAddress returns for the current device.
+constexpr size_t kStaticRows = SLAM_AMD_NOALLOC_MAX_QUERIES;
+constexpr size_t kStaticBestBytes = kStaticRows * sizeof(unsigned);
+constexpr size_t kStaticPartBytes = kStaticRows * kMaxSecondSplits * sizeof(uint2);
+static __device__ __align__(256) unsigned char scratch[kStaticBestBytes + kStaticPartBytes];
 
 extern "C" int slam_amd_matcher_create(int device, slam_amd_matcher** out) {
     if (!out) SA_FAIL(SLAM_AMD_ERR_ARG, "out is null");
@@ -496,6 +505,15 @@ extern "C" int slam_amd_matcher_create(int device, slam_amd_matcher** out) {
         m->n_cu = cu;
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete m; return hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__); }
+    // `device` is current (use_device): this is that GPU's copy of the array
+    void* sp = nullptr;
+    e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !sp) {
+        (void)hipStreamDestroy(m->stream);
+        delete m;
+        return hip_fail(e != hipSuccess ? e : hipErrorInvalidSymbol, "hipGetSymbolAddress(scratch)", __FILE__, __LINE__);
+    }
+    m->static_scratch = static_cast<unsigned char*>(sp);
     *out = m;
     return SLAM_AMD_OK;
 }
@@ -593,7 +611,7 @@ static int match_common(slam_amd_matcher* m, int batch,
                         const uint8_t* d2, const slam_amd_keypoint* k2, int n2, const int32_t* d_n2, int cap2,
                         const int32_t* ids, int n_ids, const float* q_xy,
                         float max_dist, float area, int max_level,
-                        slam_amd_dmatch* d_out, int32_t* d_n_out, hipStream_t st) {
+                        slam_amd_dmatch* d_out, int32_t* d_n_out, hipStream_t st, bool no_alloc = false) {
     if (!m || !d_out || !d_n_out) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
     if (n1 < 0 || n2 < 0 || n_ids < 0 || batch <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "negative size");
     if (n2 >= (1 << 20)) SA_FAIL(SLAM_AMD_ERR_ARG, "train set larger than 2^20 - 1 rows");
@@ -613,15 +631,22 @@ static int match_common(slam_amd_matcher* m, int batch,
     // With the window gate on and sets large enough to repay the reordering, both sets
     // are sorted by grid cell and only nearby tiles are compared; same result.
     bool windowed = area > 0.f && area <= 3.0e38f && nq > 0 && n2 > 0;
-    if (m->window_mode == 1) windowed = false;
+    if (m->window_mode == 1 || no_alloc) windowed = false;   // the full sweep needs no reordered copies
     else if (m->window_mode == 0) windowed = windowed && (long long)nq * n2 >= (1LL << 25);
     MatchPlan plan = plan_match(batch, nq, n2, m->n_cu, second);
     if (windowed) plan.splits = window_splits(batch, nq, n2, m->n_cu);
     int rc;
-    const bool capturing = stream_capturing(st);
+    const bool capturing = !no_alloc && stream_capturing(st);
     unsigned* best_p;
     uint2* part_p;
-    {
+    if (no_alloc) {
+        // the per-device static array instead of the matcher's own buffers; nothing is allocated
+        if (rows > kStaticRows)
+            SA_FAIL(SLAM_AMD_ERR_CAPACITY, "slam_amd_frame_match_noalloc_async: more than "
+                                           "SLAM_AMD_NOALLOC_MAX_QUERIES (32768) query rows");
+        best_p = reinterpret_cast<unsigned*>(m->static_scratch);
+        part_p = reinterpret_cast<uint2*>(m->static_scratch + kStaticBestBytes);
+    } else {
         if (second) { if ((rc = grow_scratch(m, m->part, fill_bytes(rows * plan.splits * sizeof(uint2)), capturing))) return rc; }
         else if ((rc = grow_scratch(m, m->best, fill_bytes(rows * sizeof(unsigned)), capturing))) return rc;
         best_p = m->best.as<unsigned>();
@@ -701,6 +726,20 @@ extern "C" int slam_amd_frame_match_async(slam_amd_matcher* m,
     return match_common(m, 1, d_desc1, d_kp1, n1, d_n1, cap1, d_desc2, d_kp2, n2, d_n2, std::max(n2, 1),
                         d_ids, n_ids, d_q_xy, max_dist, area, max_level, d_out, d_n_out,
                         reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int slam_amd_frame_match_noalloc_async(slam_amd_matcher* m,
+                                                  const uint8_t* d_desc1, const slam_amd_keypoint* d_kp1, int n1,
+                                                  const int32_t* d_n1,
+                                                  const uint8_t* d_desc2, const slam_amd_keypoint* d_kp2, int n2,
+                                                  const int32_t* d_n2,
+                                                  const int32_t* d_ids, int n_ids, const float* d_q_xy,
+                                                  float max_dist, float area, int max_level,
+                                                  slam_amd_dmatch* d_out, int32_t* d_n_out, void* stream) {
+    const int cap1 = std::max(d_ids ? std::max(n_ids, n1) : n1, 1);
+    return match_common(m, 1, d_desc1, d_kp1, n1, d_n1, cap1, d_desc2, d_kp2, n2, d_n2, std::max(n2, 1),
+                        d_ids, n_ids, d_q_xy, max_dist, area, max_level, d_out, d_n_out,
+                        reinterpret_cast<hipStream_t>(stream), true);
 }
 
 extern "C" int slam_amd_frame_match_batch_async(slam_amd_matcher* m, int batch,
