@@ -69,6 +69,10 @@ def test_extract_capacity_and_errors(oracle, capi):
     with pytest.raises(capi.SlamAmdError) as e:          # caller buffer too small: nothing written
         ex.extract(img, capacity=n - 1)
     assert e.value.status == capi.ERR_CAPACITY
+    kp, d = ex.extract_fetch(n)                           # ... and fetched afterwards without a second extraction
+    assert kp.tobytes() == kp_o.tobytes() and np.array_equal(d, d_o)
+    with pytest.raises(capi.SlamAmdError):
+        ex.extract_fetch(n - 1)
     kp, d = ex.extract(img, capacity=n)                   # exactly enough
     assert kp.tobytes() == kp_o.tobytes() and np.array_equal(d, d_o)
     with pytest.raises(capi.SlamAmdError) as e:          # wrong image size
