@@ -348,6 +348,13 @@ void slam_amd_sincos_f32(float angle_rad, float* cos_out, float* sin_out);
 float slam_amd_fast_atan2(float y, float x);
 /* INTER_LINEAR_EXACT tables of one axis as the pyramid kernel receives them. */
 int slam_amd_linear_exact_coeffs(int src_size, int dst_size, int32_t* offsets, uint16_t* c1);
+/* Launch plan of the pyramid kernel for an image size (pure host computation, no GPU needed).
+ * *n_groups = number of launches; for `group`: info6 = {first level, last level, tile size of the
+ * last level, tiles in x, tiles in y, LDS bytes}; spanx / spany = for every tile and slot (slot 0 =
+ * the source level first - 1, slot k = level first + k - 1) the range computed [c0, c1) and the range
+ * owned (stored) [o0, o1) as 4 int16 each, [tiles][last - first + 2][4].  Any pointer may be NULL. */
+int slam_amd_debug_pyramid_plan(const slam_amd_orb_params* params, int width, int height, int group,
+                                int* n_groups, int* info6, int16_t* spanx, int16_t* spany, int span_capacity);
 /* Host-side table of cv::resize(INTER_LINEAR) for 8-bit images, one axis: source
  * offset and the two 11-bit taps per destination index (clamp_frac: horizontal rule). */
 int slam_amd_linear_taps(int src_size, int dst_size, double inv_scale, int clamp_frac,

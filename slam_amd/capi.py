@@ -39,7 +39,7 @@ EXPORTS = [
     "slam_amd_frontend_create", "slam_amd_frontend_destroy", "slam_amd_frontend_output_size",
     "slam_amd_frontend_run_async", "slam_amd_frontend_run", "slam_amd_linear_taps",
     "slam_amd_prof_enable", "slam_amd_prof_collect", "slam_amd_prof_stage_name",
-    "slam_amd_sincos_f32", "slam_amd_fast_atan2", "slam_amd_linear_exact_coeffs",
+    "slam_amd_sincos_f32", "slam_amd_fast_atan2", "slam_amd_linear_exact_coeffs", "slam_amd_debug_pyramid_plan",
 ]
 PROF_STAGES = 10
 
@@ -152,6 +152,25 @@ def linear_taps(src_size, dst_size, inv_scale, clamp_frac):
     lib().slam_amd_linear_taps.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
     check(lib().slam_amd_linear_taps(src_size, dst_size, float(inv_scale), int(clamp_frac), _ptr(ofs), _ptr(taps)))
     return ofs, taps
+
+
+def pyramid_plan(params, width, height):
+    """Launch plan of the pyramid kernel (host computation): list of dicts per launch with
+    first, last, tile, ntx, nty, lds_bytes, spanx [ntx][slots][4], spany [nty][slots][4]."""
+    n = C.c_int(0)
+    fn = lib().slam_amd_debug_pyramid_plan
+    fn.argtypes = [C.POINTER(OrbParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    check(fn(C.byref(params), width, height, -1, C.byref(n), None, None, None, 0))
+    out = []
+    for g in range(n.value):
+        info = np.zeros(6, np.int32)
+        check(fn(C.byref(params), width, height, g, None, _ptr(info), None, None, 0))
+        first, last, tile, ntx, nty, lds = [int(v) for v in info]
+        slots = last - first + 2
+        sx = np.zeros((ntx, slots, 4), np.int16); sy = np.zeros((nty, slots, 4), np.int16)
+        check(fn(C.byref(params), width, height, g, None, None, _ptr(sx), _ptr(sy), max(sx.size, sy.size)))
+        out.append(dict(first=first, last=last, tile=tile, ntx=ntx, nty=nty, lds_bytes=lds, spanx=sx, spany=sy))
+    return out
 
 
 def sincos_f32(angle_rad):

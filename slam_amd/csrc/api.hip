@@ -90,13 +90,17 @@ struct slam_amd_extractor {
     slam_amd_orb_params params;
     int width = 0, height = 0, max_batch = 0, max_keypoints = 0, device = 0;
     PyrGeom g;
-    // per level (>= 1) resize tables on the device and LDS footprint
+    // pyramid: per level (>= 1) coefficient tables on the device and the launch plan (groups of
+    // levels chained inside one kernel, regions per tile of each group's last level)
     DevBuf tables;
-    const int* xoff[kMaxLevels] = {};
-    const uint16_t* xc1[kMaxLevels] = {};
-    const int* yoff[kMaxLevels] = {};
-    const uint16_t* yc1[kMaxLevels] = {};
-    int lds_pitch[kMaxLevels] = {}, lds_rows[kMaxLevels] = {};
+    const uint32_t* xtab[kMaxLevels] = {};
+    const uint32_t* ytab[kMaxLevels] = {};
+    struct PyrGroupPlan {
+        int first, last, ntx, nty, tabcap, buf_even, buf_odd;
+        const PyrSpan* spanx; const PyrSpan* spany;
+        size_t lds_bytes;
+    };
+    std::vector<PyrGroupPlan> pyr_groups;
     DevBuf pyr, smap, blur, hist, rowlist, sel, kpxy;  // hist also holds the row fill counters
     // host-call staging
     DevBuf h_img, h_kp, h_desc, h_count;
@@ -143,9 +147,10 @@ static void linear_exact_axis(int src, int dst, bool exact_half, int32_t* off, u
     }
 }
 
-static int build_geometry(slam_amd_extractor* ex) {
-    const slam_amd_orb_params& p = ex->params;
-    PyrGeom& g = ex->g;
+static int build_geometry_of(const slam_amd_orb_params& p, int width, int height, PyrGeom& g);
+static int build_geometry(slam_amd_extractor* ex) { return build_geometry_of(ex->params, ex->width, ex->height, ex->g); }
+
+static int build_geometry_of(const slam_amd_orb_params& p, int width, int height, PyrGeom& g) {
     memset(&g, 0, sizeof g);
     g.nlevels = p.nlevels;
     g.edge = p.edge_threshold;
@@ -160,8 +165,8 @@ static int build_geometry(slam_amd_extractor* ex) {
         LevelGeom& L = g.lv[l];
         L.scale = (float)pow((double)p.scale_factor, (double)l);
         L.inv_scale = 1.0f / L.scale;
-        L.w = (int)lrintf((float)ex->width * L.inv_scale);
-        L.h = (int)lrintf((float)ex->height * L.inv_scale);
+        L.w = (int)lrintf((float)width * L.inv_scale);
+        L.h = (int)lrintf((float)height * L.inv_scale);
         if (L.w <= 0 || L.h <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "image too small for the number of levels");
         L.size = (float)p.patch_size * L.scale;
         if (l < p.nlevels - 1) {
@@ -187,52 +192,177 @@ static int build_geometry(slam_amd_extractor* ex) {
     return SLAM_AMD_OK;
 }
 
+// ---- pyramid plan ------------------------------------------------------------------------
+// Regions of one axis for a group of levels [first, last] and `nt` tiles of `T` pixels of level
+// `last`.  slot 0 is the source level first - 1, slot k the level first + k - 1.  Every tile owns
+// [o0, o1) of each level (the tiles' shares partition the level) and computes [c0, c1): its share
+// plus whatever the next level's computed range reads.  off[l][d] is the source index of
+// destination index d of level l (padded by replication past the level size).
+struct AxisPlan {
+    std::vector<PyrSpan> span;   // [nt][slots]
+    int max_len_even = 0, max_len_odd = 0, max_tab = 0;
+};
+
+static AxisPlan plan_axis(const std::vector<std::vector<int32_t>>& off, const int* size, int first, int last,
+                          int T, int nt, bool is_x) {
+    const int slots = last - first + 2;
+    AxisPlan ap;
+    ap.span.resize((size_t)nt * slots);
+    auto up4 = [](int v) { return (v + 3) & ~3; };
+    for (int i = 0; i < nt; i++) {
+        PyrSpan* sp = &ap.span[(size_t)i * slots];
+        int need0 = 0, need1 = 0;   // needed range of the level above (slot k + 1), exact
+        for (int k = slots - 1; k >= 0; k--) {
+            const int l = first + k - 1;
+            const int n = size[l];
+            const int padded = is_x ? up4(n) : n;     // x: whole dwords are produced and stored
+            int o0 = 0, o1 = 0;
+            if (k >= 1) {
+                auto bound = [&](int t) {
+                    if (t <= 0) return 0;
+                    if (t >= nt) return padded;
+                    long long v = ((long long)t * T * n + size[last] / 2) / size[last];
+                    int r = is_x ? (int)(v + 2) & ~3 : (int)v;
+                    return std::min(std::max(r, 0), padded);
+                };
+                o0 = bound(i); o1 = bound(i + 1);
+            }
+            int lo, hi;
+            if (k == slots - 1) { lo = o0; hi = o1; }
+            else {
+                // what the next level's needed range reads: both taps of its first and last index
+                lo = off[l + 1][need0];
+                hi = off[l + 1][need1 - 1] + 2;
+                if (k >= 1 && o1 > o0) { lo = std::min(lo, o0); hi = std::max(hi, o1); }
+            }
+            if (hi <= lo) { lo = 0; hi = 2; }   // a tile without a share still stages a stub
+            need0 = lo; need1 = hi;
+            // computed range: the needed one widened to whole dwords in x (the extra positions are
+            // produced from clamped source indices and never used)
+            const int c0 = is_x ? (lo & ~3) : lo, c1 = is_x ? up4(hi) : hi;
+            sp[k].c0 = (short)c0; sp[k].c1 = (short)c1; sp[k].o0 = (short)o0; sp[k].o1 = (short)o1;
+            const int len = c1 - c0;
+            if (k & 1) ap.max_len_odd = std::max(ap.max_len_odd, len); else ap.max_len_even = std::max(ap.max_len_even, len);
+            if (k >= 1) ap.max_tab = std::max(ap.max_tab, len);
+        }
+    }
+    return ap;
+}
+
+struct HostGroup { int first, last, T, ntx, nty; AxisPlan ax, ay; size_t lds; };
+struct HostPyramidPlan {
+    std::vector<std::vector<uint32_t>> xt, yt;   // per level
+    std::vector<HostGroup> groups;
+};
+
+static int make_pyramid_plan(const PyrGeom& g, HostPyramidPlan& plan) {
+    plan.xt.assign(g.nlevels, {}); plan.yt.assign(g.nlevels, {}); plan.groups.clear();
+    if (g.nlevels < 2) return SLAM_AMD_OK;
+    std::vector<std::vector<uint32_t>>& xt = plan.xt;
+    std::vector<std::vector<uint32_t>>& yt = plan.yt;
+    std::vector<HostGroup>& groups = plan.groups;
+    // per level l >= 1: (source index | 8.8 weight of the second tap << 16) per destination index,
+    // padded by replicating the last entry so that whole dwords of a row can be produced
+    std::vector<std::vector<int32_t>> xo(g.nlevels), yo(g.nlevels);
+    int ws[kMaxLevels], hs[kMaxLevels];
+    for (int l = 0; l < g.nlevels; l++) { ws[l] = g.lv[l].w; hs[l] = g.lv[l].h; }
+    constexpr int kPad = 8;
+    for (int l = 1; l < g.nlevels; l++) {
+        const int sw = ws[l - 1], sh = hs[l - 1], dw = ws[l], dh = hs[l];
+        const bool half = (sw == 2 * dw) && (sh == 2 * dh);
+        std::vector<int32_t> o(std::max(dw, dh));
+        std::vector<uint16_t> c(std::max(dw, dh));
+        auto fill = [&](int src, int dst, std::vector<int32_t>& offs, std::vector<uint32_t>& tab) {
+            linear_exact_axis(src, dst, half, o.data(), c.data());
+            offs.resize((size_t)dst + kPad); tab.resize((size_t)dst + kPad);
+            for (int d = 0; d < dst + kPad; d++) {
+                const int e = std::min(d, dst - 1);
+                if (o[e] > 0xffff) return false;
+                offs[d] = o[e];
+                tab[d] = (uint32_t)o[e] | ((uint32_t)c[e] << 16);
+            }
+            return true;
+        };
+        if (!fill(sw, dw, xo[l], xt[l]) || !fill(sh, dh, yo[l], yt[l])) SA_FAIL(SLAM_AMD_ERR_ARG, "image too large");
+    }
+    // groups of consecutive levels whose regions fit the LDS budget, tiles of 32 (else 16, 8) pixels
+    constexpr size_t kLdsBudget = 48 * 1024;
+    auto try_group = [&](int first, int last, int T, HostGroup& out) {
+        out.first = first; out.last = last; out.T = T;
+        out.ntx = div_up(ws[last], T); out.nty = div_up(hs[last], T);
+        out.ax = plan_axis(xo, ws, first, last, T, out.ntx, true);
+        out.ay = plan_axis(yo, hs, first, last, T, out.nty, false);
+        const int tabcap = (std::max(out.ax.max_tab, out.ay.max_tab) + 3) & ~3;
+        const size_t even = (size_t)out.ax.max_len_even * out.ay.max_len_even, odd = (size_t)out.ax.max_len_odd * out.ay.max_len_odd;
+        out.lds = (size_t)(last - first + 1) * tabcap * 8 + ((even + 15) & ~(size_t)15) + ((odd + 15) & ~(size_t)15);
+        const int widest = std::max(out.ax.max_len_even, out.ax.max_len_odd);
+        return out.lds <= kLdsBudget && widest <= 1020;
+    };
+    for (int first = 1; first < g.nlevels;) {
+        HostGroup best;
+        bool found = false;
+        for (int T : {32, 16, 8}) {
+            // the longest run of levels from `first` that fits with this tile size; larger tiles
+            // are preferred (fewer, larger workgroups: less recomputation at the tile borders)
+            int last = first;
+            HostGroup cand;
+            while (last < g.nlevels && try_group(first, last, T, cand)) { best = cand; found = true; last++; }
+            if (found) break;
+        }
+        if (!found) SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "scale factor too large for the pyramid kernel");
+        groups.push_back(best);
+        first = best.last + 1;
+    }
+    return SLAM_AMD_OK;
+}
+
 static int build_tables(slam_amd_extractor* ex) {
     const PyrGeom& g = ex->g;
-    // layout: per level l >= 1: xoff[w] yoff[h] (int32) then xc1[w] yc1[h] (uint16), 16-byte aligned
+    ex->pyr_groups.clear();
+    HostPyramidPlan plan;
+    int prc = make_pyramid_plan(g, plan);
+    if (prc) return prc;
+    if (g.nlevels < 2) return SLAM_AMD_OK;
+    std::vector<std::vector<uint32_t>>& xt = plan.xt;
+    std::vector<std::vector<uint32_t>>& yt = plan.yt;
+    std::vector<HostGroup>& groups = plan.groups;
+    // one device allocation: tables of every level, then the spans of every group
     std::vector<uint8_t> host;
-    std::vector<size_t> o_xoff(g.nlevels), o_yoff(g.nlevels), o_xc(g.nlevels), o_yc(g.nlevels);
-    auto reserve = [&](size_t bytes) { size_t o = (host.size() + 15) & ~(size_t)15; host.resize(o + bytes); return o; };
+    auto put = [&](const void* src, size_t bytes) {
+        const size_t o = (host.size() + 15) & ~(size_t)15;
+        host.resize(o + bytes);
+        memcpy(host.data() + o, src, bytes);
+        return o;
+    };
+    size_t o_xt[kMaxLevels] = {}, o_yt[kMaxLevels] = {};
     for (int l = 1; l < g.nlevels; l++) {
-        const int sw = g.lv[l - 1].w, sh = g.lv[l - 1].h, dw = g.lv[l].w, dh = g.lv[l].h;
-        o_xoff[l] = reserve(sizeof(int32_t) * dw);
-        o_yoff[l] = reserve(sizeof(int32_t) * dh);
-        o_xc[l] = reserve(sizeof(uint16_t) * dw);
-        o_yc[l] = reserve(sizeof(uint16_t) * dh);
-        int32_t* xo = reinterpret_cast<int32_t*>(host.data() + o_xoff[l]);
-        int32_t* yo = reinterpret_cast<int32_t*>(host.data() + o_yoff[l]);
-        uint16_t* xc = reinterpret_cast<uint16_t*>(host.data() + o_xc[l]);
-        uint16_t* yc = reinterpret_cast<uint16_t*>(host.data() + o_yc[l]);
-        const bool half = (sw == 2 * dw) && (sh == 2 * dh);
-        linear_exact_axis(sw, dw, half, xo, xc);
-        linear_exact_axis(sh, dh, half, yo, yc);
-        // LDS footprint of the widest / tallest destination tile
-        int max_cols = 0, max_rows = 0;
-        for (int x0 = 0; x0 < dw; x0 += 128) {
-            const int xl = std::min(x0 + 128, dw) - 1;
-            const int s0 = xo[x0] & ~3, s1 = std::min(xo[xl] + 1, sw - 1);
-            max_cols = std::max(max_cols, ((s1 - s0) / 4 + 1) * 4);
-        }
-        for (int y0 = 0; y0 < dh; y0 += 16) {
-            const int yl = std::min(y0 + 16, dh) - 1;
-            const int s0 = yo[y0], s1 = std::min(yo[yl] + 1, sh - 1);
-            max_rows = std::max(max_rows, s1 - s0 + 1);
-        }
-        ex->lds_pitch[l] = max_cols + 4;
-        ex->lds_rows[l] = max_rows;
-        if ((size_t)ex->lds_pitch[l] * ex->lds_rows[l] > 64 * 1024)
-            SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "scale factor too large for the resize tile");
+        o_xt[l] = put(xt[l].data(), xt[l].size() * 4);
+        o_yt[l] = put(yt[l].data(), yt[l].size() * 4);
     }
-    if (host.empty()) host.resize(16);
+    std::vector<size_t> o_sx(groups.size()), o_sy(groups.size());
+    for (size_t i = 0; i < groups.size(); i++) {
+        o_sx[i] = put(groups[i].ax.span.data(), groups[i].ax.span.size() * sizeof(PyrSpan));
+        o_sy[i] = put(groups[i].ay.span.data(), groups[i].ay.span.size() * sizeof(PyrSpan));
+    }
     int rc = ex->tables.reserve(host.size());
     if (rc) return rc;
     SA_HIP(hipMemcpy(ex->tables.p, host.data(), host.size(), hipMemcpyHostToDevice));
     const uint8_t* base = ex->tables.as<uint8_t>();
     for (int l = 1; l < g.nlevels; l++) {
-        ex->xoff[l] = reinterpret_cast<const int*>(base + o_xoff[l]);
-        ex->yoff[l] = reinterpret_cast<const int*>(base + o_yoff[l]);
-        ex->xc1[l] = reinterpret_cast<const uint16_t*>(base + o_xc[l]);
-        ex->yc1[l] = reinterpret_cast<const uint16_t*>(base + o_yc[l]);
+        ex->xtab[l] = reinterpret_cast<const uint32_t*>(base + o_xt[l]);
+        ex->ytab[l] = reinterpret_cast<const uint32_t*>(base + o_yt[l]);
+    }
+    for (size_t i = 0; i < groups.size(); i++) {
+        const HostGroup& hg = groups[i];
+        slam_amd_extractor::PyrGroupPlan pg;
+        pg.first = hg.first; pg.last = hg.last; pg.ntx = hg.ntx; pg.nty = hg.nty;
+        pg.tabcap = (std::max(hg.ax.max_tab, hg.ay.max_tab) + 3) & ~3;
+        pg.buf_even = (int)(((size_t)hg.ax.max_len_even * hg.ay.max_len_even + 15) & ~(size_t)15);
+        pg.buf_odd = (int)(((size_t)hg.ax.max_len_odd * hg.ay.max_len_odd + 15) & ~(size_t)15);
+        pg.spanx = reinterpret_cast<const PyrSpan*>(base + o_sx[i]);
+        pg.spany = reinterpret_cast<const PyrSpan*>(base + o_sy[i]);
+        pg.lds_bytes = hg.lds;
+        ex->pyr_groups.push_back(pg);
     }
     return SLAM_AMD_OK;
 }
@@ -333,20 +463,16 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     }
     int rc;
     prof_mark(kStageResize, true, st);
-    for (int l = 1; l < g.nlevels; l++) {
-        ResizeArgs a;
-        if (l == 1) {
-            a.src = d_images; a.src_frame_pitch = frame_pitch; a.src_pitch = row_stride; a.src_aligned = aligned;
-        } else {
-            a.src = ex->pyr.as<uint8_t>() + g.lv[l - 1].off; a.src_frame_pitch = g.frame_bytes;
-            a.src_pitch = g.lv[l - 1].pitch; a.src_aligned = 1;
-        }
-        a.sw = g.lv[l - 1].w; a.sh = g.lv[l - 1].h;
-        a.dst = ex->pyr.as<uint8_t>() + g.lv[l].off; a.dst_frame_pitch = g.frame_bytes;
-        a.dst_pitch = g.lv[l].pitch; a.dw = g.lv[l].w; a.dh = g.lv[l].h;
-        a.xoff = ex->xoff[l]; a.xc1 = ex->xc1[l]; a.yoff = ex->yoff[l]; a.yc1 = ex->yc1[l];
-        a.lds_pitch = ex->lds_pitch[l]; a.lds_rows = ex->lds_rows[l];
-        if ((rc = launch_resize(a, batch, st))) return rc;
+    for (const slam_amd_extractor::PyrGroupPlan& pg : ex->pyr_groups) {
+        PyramidArgs a;
+        memset(&a, 0, sizeof a);
+        a.src0 = d_images; a.src0_frame_pitch = frame_pitch; a.src0_pitch = row_stride; a.src0_aligned = aligned;
+        a.pyr = ex->pyr.as<uint8_t>(); a.g = g;
+        a.first = pg.first; a.last = pg.last; a.ntx = pg.ntx; a.nty = pg.nty;
+        a.spanx = pg.spanx; a.spany = pg.spany;
+        for (int l = 1; l < g.nlevels; l++) { a.xtab[l] = ex->xtab[l]; a.ytab[l] = ex->ytab[l]; }
+        a.tabcap = pg.tabcap; a.buf_even = pg.buf_even; a.buf_odd = pg.buf_odd;
+        if ((rc = launch_pyramid(a, batch, pg.lds_bytes, st))) return rc;
     }
     prof_mark(kStageResize, false, st);
     FastArgs fa;
@@ -1093,7 +1219,7 @@ extern "C" int slam_amd_prof_collect(double* total_ms, int* calls, int n_stages)
 }
 
 extern "C" const char* slam_amd_prof_stage_name(int stage) {
-    static const char* names[kStageCount] = {"resize_level (all levels)", "fast_nms", "select_compact",
+    static const char* names[kStageCount] = {"pyramid (all levels)", "fast_nms", "select_compact",
         "spatial_sort", "match_window", "describe", "match", "finalize_matches", "match_pairs", "memset"};
     return (stage >= 0 && stage < kStageCount) ? names[stage] : "";
 }
@@ -1142,6 +1268,26 @@ extern "C" int slam_amd_linear_taps(int src_size, int dst_size, double inv_scale
                                     int32_t* offsets, int16_t* taps) {
     if (src_size <= 0 || dst_size <= 0 || !(inv_scale > 0) || !offsets || !taps) SA_FAIL(SLAM_AMD_ERR_ARG, "bad argument");
     linear_taps_axis(src_size, dst_size, inv_scale, clamp_frac != 0, offsets, taps);
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_debug_pyramid_plan(const slam_amd_orb_params* params, int width, int height, int group,
+                                           int* n_groups, int* info6, int16_t* spanx, int16_t* spany, int span_capacity) {
+    int rc = check_orb_params(params);
+    if (rc) return rc;
+    if (width <= 0 || height <= 0 || width > 16383 || height > 16383) SA_FAIL(SLAM_AMD_ERR_ARG, "image size out of range");
+    PyrGeom g;
+    if ((rc = build_geometry_of(*params, width, height, g))) return rc;
+    HostPyramidPlan plan;
+    if ((rc = make_pyramid_plan(g, plan))) return rc;
+    if (n_groups) *n_groups = (int)plan.groups.size();
+    if (group < 0 || group >= (int)plan.groups.size()) return SLAM_AMD_OK;
+    const HostGroup& hg = plan.groups[(size_t)group];
+    if (info6) { info6[0] = hg.first; info6[1] = hg.last; info6[2] = hg.T; info6[3] = hg.ntx; info6[4] = hg.nty; info6[5] = (int)hg.lds; }
+    const size_t nx = hg.ax.span.size() * 4, ny = hg.ay.span.size() * 4;
+    if ((spanx && nx > (size_t)span_capacity) || (spany && ny > (size_t)span_capacity)) SA_FAIL(SLAM_AMD_ERR_CAPACITY, "span buffer too small");
+    if (spanx) memcpy(spanx, hg.ax.span.data(), nx * sizeof(int16_t));
+    if (spany) memcpy(spany, hg.ay.span.data(), ny * sizeof(int16_t));
     return SLAM_AMD_OK;
 }
 

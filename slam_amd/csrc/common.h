@@ -81,4 +81,15 @@ constexpr int kFastTileH = 32;
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence over
+// every address space: it also waits until the wave's outstanding global stores and atomics have
+// completed (s_waitcnt vmcnt(0)), which costs microseconds per barrier in a kernel that streams
+// results to memory between LDS phases.  Where only LDS data is handed between the waves, waiting
+// for the LDS counter is enough.
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 }  // namespace sa

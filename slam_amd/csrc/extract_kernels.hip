@@ -1,7 +1,7 @@
 // HIP kernels of the ORB extraction path for gfx950 (wave64, LDS-staged tiles).
 //
 // Per batch of frames, in stream order:
-//   resize_level  x (nlevels-1)  chained bit-exact bilinear pyramid
+//   pyramid       (pyramid_kernels.hip) chained bit-exact bilinear pyramid
 //   fast_nms                      FAST-9/16 score + 3x3 NMS + border filter + per-level score
 //                                 histogram + per-row survivor lists + 7x7 blur, all levels, one launch
 //   select_compact                per-level cut score from the histogram (retain-best), then
@@ -14,87 +14,6 @@
 #include "kernels.h"
 
 namespace sa {
-
-// ---------------------------------------------------------------------------
-// Pyramid: INTER_LINEAR_EXACT (8.8 fixed-point taps, two passes, round at 2^15).
-// One workgroup produces a 128 x 16 destination tile; the source footprint is
-// staged in LDS with 4-byte loads, then every thread blends 2 rows x 4 pixels.
-// ---------------------------------------------------------------------------
-constexpr int kRzTileW = 128;
-constexpr int kRzTileH = 16;
-
-
-__global__ __launch_bounds__(256) void resize_level_kernel(ResizeArgs a) {
-    extern __shared__ __align__(16) uint8_t rz_lds[];
-    const int b = blockIdx.z;
-    const uint8_t* src = a.src + (size_t)b * a.src_frame_pitch;
-    uint8_t* dst = a.dst + (size_t)b * a.dst_frame_pitch;
-    const int dx0 = blockIdx.x * kRzTileW, dy0 = blockIdx.y * kRzTileH;
-    const int dx_last = min(dx0 + kRzTileW, a.dw) - 1;
-    const int dy_last = min(dy0 + kRzTileH, a.dh) - 1;
-    const int xs0 = a.xoff[dx0] & ~3;
-    const int xs1 = min(a.xoff[dx_last] + 1, a.sw - 1);
-    const int ys0 = a.yoff[dy0];
-    const int ys1 = min(a.yoff[dy_last] + 1, a.sh - 1);
-    const int ncols4 = (xs1 - xs0) / 4 + 1;  // dwords per staged row
-    const int nrows = ys1 - ys0 + 1;
-    // Stage the source footprint in whole dwords (bytes past the image width are
-    // read one by one, so nothing outside the image is touched).
-    if (a.src_aligned) {
-        for (int i = threadIdx.x; i < ncols4 * nrows; i += 256) {
-            int r = i / ncols4, c = i - r * ncols4;
-            const uint8_t* p = src + (size_t)(ys0 + r) * a.src_pitch + xs0 + 4 * c;
-            uint32_t v;
-            if (xs0 + 4 * c + 3 < a.sw) {
-                v = *reinterpret_cast<const uint32_t*>(p);
-            } else {
-                v = 0;
-                for (int j = 0; j < 4; j++)
-                    if (xs0 + 4 * c + j < a.sw) v |= (uint32_t)p[j] << (8 * j);
-            }
-            *reinterpret_cast<uint32_t*>(rz_lds + r * a.lds_pitch + 4 * c) = v;
-        }
-    } else {
-        const int ncols = xs1 - xs0 + 1;
-        for (int i = threadIdx.x; i < ncols * nrows; i += 256) {
-            int r = i / ncols, c = i - r * ncols;
-            rz_lds[r * a.lds_pitch + c] = src[(size_t)(ys0 + r) * a.src_pitch + xs0 + c];
-        }
-    }
-    __syncthreads();
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int x = dx0 + 4 * tx;
-    if (x >= a.dw) return;
-    int xo[4], w1[4], xn[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int xx = min(x + j, a.dw - 1);
-        int o = a.xoff[xx];
-        xo[j] = o - xs0;
-        xn[j] = min(o + 1, a.sw - 1) - xs0;
-        w1[j] = a.xc1[xx];
-    }
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const int y = dy0 + ty + 8 * rr;
-        if (y >= a.dh) break;
-        const int yo = a.yoff[y];
-        const uint8_t* r0 = rz_lds + (yo - ys0) * a.lds_pitch;
-        const uint8_t* r1 = rz_lds + (min(yo + 1, a.sh - 1) - ys0) * a.lds_pitch;
-        const uint32_t m1 = a.yc1[y], m0 = 256 - m1;
-        uint32_t packed = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t c1 = w1[j], c0 = 256 - c1;
-            uint32_t h0 = r0[xo[j]] * c0 + r0[xn[j]] * c1;
-            uint32_t h1 = r1[xo[j]] * c0 + r1[xn[j]] * c1;
-            uint32_t v = (h0 * m0 + h1 * m1 + 32768u) >> 16;
-            packed |= v << (8 * j);
-        }
-        // The pitch is a multiple of 64, so the full dword is inside the row.
-        *reinterpret_cast<uint32_t*>(dst + (size_t)y * a.dst_pitch + x) = packed;
-    }
-}
 
 // ---------------------------------------------------------------------------
 // FAST-9/16 + NMS + blur.  A workgroup owns a 64 x 32 tile of one level of one
@@ -112,11 +31,12 @@ __global__ __launch_bounds__(256) void resize_level_kernel(ResizeArgs a) {
 // The lists keep the expensive phases dense instead of divergent.
 // ---------------------------------------------------------------------------
 constexpr int kImgHalo = 4;
-constexpr int kImgPitch = kFastTileW + 2 * kImgHalo;  // 72
+constexpr int kImgPitch = kFastTileW + 2 * kImgHalo + 4;  // 72 staged columns; 19 dwords per row, odd, so that
+                                                          // the rows of a column fall into different LDS banks
 constexpr int kImgRows = kFastTileH + 2 * kImgHalo;   // 40
 constexpr int kScW = kFastTileW + 2;                  // 66 scored columns
 constexpr int kScRows = kFastTileH + 2;               // 34 scored rows
-constexpr int kScPitch = 72;                          // LDS column = tile column + 4
+constexpr int kScPitch = kImgPitch;                   // LDS column = tile column + 4
 constexpr int kScN = kScW * kScRows;                  // 2244 positions
 constexpr int kRowRows = kFastTileH + 6;              // 38 rows of the blur row pass
 constexpr int kListBytes = ((kScN * 2 + 15) / 16) * 16;
@@ -263,13 +183,19 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     const int t = a.g.fast_threshold;
+    const int edge = a.g.edge;
+    const bool level_ok = (w > 2 * edge) && (h > 2 * edge);
     // ---- phase 1: compass test, 4 pixels per item, packed 16-bit arithmetic ----
     // Item (row r of the scored region, column group cg) covers staged columns
     // 4cg .. 4cg+3 of staged row r + 3.  With d = centre - compass pixel for the four
-    // compass points, a 9-arc needs two of them beyond the threshold on one side:
-    // second largest d > t (darker) or second smallest d < -t (brighter).
+    // compass points: an arc of 9 of the 16 ring pixels holds at least one pixel of every
+    // opposite pair, so a darker arc needs max(d0, d8) > t and max(d4, d12) > t, a brighter
+    // one min(d0, d8) < -t and min(d4, d12) < -t.
+    // Only positions that can matter are tested: a keypoint lies at least `edge` pixels from
+    // the level border and its 3x3 suppression looks one pixel further, so scores outside
+    // [edge - 1, size - edge] are never read (edge >= 31 > 3, the FAST margin).
 #pragma unroll
     for (int it = 0; it < 3; it++) {
         const int r = rr + 14 * it;
@@ -296,19 +222,20 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
                 const ss2 d12 = c - as_ss2(__builtin_amdgcn_perm(0u, L, sel));
                 const ss2 hi1 = __builtin_elementwise_max(d0, d8), lo1 = __builtin_elementwise_min(d0, d8);
                 const ss2 hi2 = __builtin_elementwise_max(d4, d12), lo2 = __builtin_elementwise_min(d4, d12);
-                const ss2 m1 = __builtin_elementwise_min(hi1, hi2), m2 = __builtin_elementwise_max(lo1, lo2);
-                const ss2 second_hi = __builtin_elementwise_max(m1, m2), second_lo = __builtin_elementwise_min(m1, m2);
+                // the smaller of the two pair maxima / the larger of the two pair minima
+                const ss2 dark = __builtin_elementwise_min(hi1, hi2), bright = __builtin_elementwise_max(lo1, lo2);
                 // sign bit of each 16-bit half set <=> that pixel passes
-                f[hf] = as_u32s(T2 - second_hi) | as_u32s(second_lo + T2);
+                f[hf] = as_u32s(T2 - dark) | as_u32s(bright + T2);
             }
             pass4 = ((f[0] >> 15) & 1u) | ((f[0] >> 30) & 2u) | ((f[1] >> 13) & 4u) | ((f[1] >> 28) & 8u);
             // positions outside the scored region or within 3 pixels of the image edge
             const int col0 = 4 * cg;                    // staged column of pixel 0
             const int gx0 = x0 - kImgHalo + col0;
             const int gy = y0 - 1 + r;
-            int jmin = max(3 - col0, 3 - gx0), jmax = min(69 - col0, (w - 3) - gx0);
+            int jmin = max(3 - col0, (edge - 1) - gx0), jmax = min(69 - col0, (w - edge + 1) - gx0);
             jmin = max(jmin, 0); jmax = min(jmax, 4);
-            unsigned vmask = (jmax > jmin && gy >= 3 && gy < h - 3) ? (((1u << jmax) - 1u) & ~((1u << jmin) - 1u)) : 0u;
+            unsigned vmask = (level_ok && jmax > jmin && gy >= edge - 1 && gy < h - edge + 1)
+                                 ? (((1u << jmax) - 1u) & ~((1u << jmin) - 1u)) : 0u;
             pass4 &= vmask;
         }
         // append the staged offsets of the passing pixels to list 1
@@ -329,7 +256,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             if (pass4 & 8u) s_list1[base + n012 + __builtin_popcountll(b3 & lt)] = (uint16_t)(code + 3);
         }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- phase 2: full ring, 9 contiguous darker or brighter ----
     // One subtract and one funnel shift per flag: the sign of (ring - (v - t)) says
     // "darker", the sign of ((v + t) - ring) "brighter"; alignbit shifts it into the mask.
@@ -357,7 +284,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         }
         list_append(corner, code, s_list2, &s_n[1]);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- phase 3: score of the corners ----
     const int n2 = (int)s_n[1];
     for (int k = tid; k < n2; k += 256) {
@@ -366,11 +293,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         ring_diffs(s_img + code, d);
         s_sc[code - 3 * kImgPitch] = (uint8_t)fast_corner_score(d, t);   // same pitch, 3 rows up
     }
-    __syncthreads();
+    lds_barrier();
     // ---- phase 4a: NMS + border filter, 4 pixels per thread ----
     uint8_t* smap = a.smap + (size_t)b * a.g.frame_bytes + L.off;
-    const int edge = a.g.edge;
-    const bool level_ok = (w > 2 * edge) && (h > 2 * edge);
     if (!a.grid_shift) {
         // the reference's selection: every NMS survivor inside the border goes on
         const int tx = tid & 15, tr = tid >> 4;
@@ -450,7 +375,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
                 }
             };
             contest(true);
-            __syncthreads();
+            lds_barrier();
             contest(false);
         }
 #pragma unroll
@@ -497,7 +422,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         s_row[r * 32 + 2 * g] = as_u32(o01);
         s_row[r * 32 + 2 * g + 1] = as_u32(o23);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- phase 5: blur column pass, 2 rows x 4 columns per thread ----
     {
         uint8_t* blur = a.blur + (size_t)b * a.g.frame_bytes + L.off;
@@ -887,14 +812,6 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
 // ---------------------------------------------------------------------------
 // Launchers (host)
 // ---------------------------------------------------------------------------
-int launch_resize(const ResizeArgs& a, int batch, hipStream_t st) {
-    dim3 grid(div_up(a.dw, kRzTileW), div_up(a.dh, kRzTileH), batch);
-    size_t lds = (size_t)a.lds_pitch * a.lds_rows;
-    hipLaunchKernelGGL(resize_level_kernel, grid, dim3(256), lds, st, a);
-    SA_HIP(hipGetLastError());
-    return SLAM_AMD_OK;
-}
-
 int launch_fast(const FastArgs& a0, int batch, hipStream_t st) {
     FastArgs a = a0;
     a.tiles_all = a.g.total_tiles * batch;

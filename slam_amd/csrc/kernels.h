@@ -5,19 +5,24 @@
 
 namespace sa {
 
-struct ResizeArgs {
-    const uint8_t* src;
-    size_t src_frame_pitch;
-    int src_pitch, sw, sh;
-    uint8_t* dst;
-    size_t dst_frame_pitch;
-    int dst_pitch, dw, dh;
-    const int* xoff;
-    const uint16_t* xc1;
-    const int* yoff;
-    const uint16_t* yc1;
-    int lds_pitch, lds_rows;
-    int src_aligned;  // 1: src base and pitch are multiples of 4
+// Range of one axis that a pyramid tile computes [c0, c1) and owns (stores) [o0, o1) at one level.
+struct PyrSpan { short c0, c1, o0, o1; };
+
+struct PyramidArgs {
+    const uint8_t* src0;       // caller's level-0 frames
+    size_t src0_frame_pitch;
+    int src0_pitch;
+    int src0_aligned;          // 1: base and pitches are multiples of 4
+    uint8_t* pyr;              // levels >= 1
+    PyrGeom g;
+    int first, last;           // levels this launch produces (first >= 1); the source is level first - 1
+    int ntx, nty;              // tiles of level `last`
+    const PyrSpan* spanx;      // [ntx][last - first + 2], slot 0 = the source level
+    const PyrSpan* spany;      // [nty][last - first + 2]
+    const uint32_t* xtab[kMaxLevels];  // per level: source index | second-tap weight << 16, padded
+    const uint32_t* ytab[kMaxLevels];
+    int tabcap;                // LDS entries reserved per coefficient slice (multiple of 4)
+    int buf_even, buf_odd;     // bytes of the LDS buffers of the even / odd slots
 };
 
 struct FastArgs {
@@ -204,7 +209,7 @@ struct DupArgs {
     uint8_t* flag;
 };
 
-int launch_resize(const ResizeArgs& a, int batch, hipStream_t st);
+int launch_pyramid(const PyramidArgs& a, int batch, size_t lds_bytes, hipStream_t st);
 int launch_fast(const FastArgs& a, int batch, hipStream_t st);
 int launch_select_compact(const SelectCompactArgs& a, int batch, hipStream_t st);
 int launch_describe(const DescribeArgs& a, int batch, hipStream_t st);

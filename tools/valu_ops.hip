@@ -1,5 +1,7 @@
-// Micro-benchmark: issue rate of single VALU opcodes on gfx950 (independent chains,
-// operands in registers) to tell which instruction bounds the Hamming inner loop.
+// Micro-benchmark: issue rate of single VALU opcodes on gfx950 (16 independent chains per lane,
+// operands in registers), to price kernels by the instructions they issue.  One line per opcode
+// and grid size: lane-ops per clock per CU (128 = one wave64 instruction every 2 cycles on each
+// of the 4 SIMD-32s).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -16,13 +18,47 @@ __global__ __launch_bounds__(256) void op_kernel(const unsigned* in, unsigned* o
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             if (OP == 0) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
-            if (OP == 1) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 1) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
             if (OP == 2) asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
-            if (OP == 3) asm volatile("v_min_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
-            if (OP == 4) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(b));
-            if (OP == 5) asm volatile("v_min3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
-            if (OP == 6) asm volatile("v_bcnt_u32_b32 %0, %0, 0" : "+v"(a[i]));
-            if (OP == 7) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 3) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 4) asm volatile("v_min_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 5) asm volatile("v_max_i32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 6) asm volatile("v_min3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 7) asm volatile("v_max3_i32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 8) asm volatile("v_med3_i32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 9) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 10) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 11) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a[i]) :);
+            if (OP == 12) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[i]) :);
+            if (OP == 13) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 14) asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 15) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 16) asm volatile("v_bfe_u32 %0, %0, 3, 8" : "+v"(a[i]) :);
+            if (OP == 17) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 18) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(a[i]) : "v"(b));
+            if (OP == 19) asm volatile("v_alignbyte_b32 %0, %0, %1, 1" : "+v"(a[i]) : "v"(b));
+            if (OP == 20) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 21) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 22) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 23) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 24) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 25) asm volatile("v_pk_mad_u16 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 26) asm volatile("v_pk_lshrrev_b16 %0, 1, %0" : "+v"(a[i]) :);
+            if (OP == 27) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 28) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 29) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 30) asm volatile("v_dot4_u32_u8 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 31) asm volatile("v_dot2_u32_u16 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 32) asm volatile("v_sad_u8 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 33) asm volatile("v_msad_u8 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 34) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+            if (OP == 35) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+            if (OP == 36) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 37) asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) :);
+            if (OP == 38) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 39) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 40) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i]) :);
+            if (OP == 41) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(a[i]) :);
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -35,7 +71,7 @@ __global__ __launch_bounds__(256) void op_kernel(const unsigned* in, unsigned* o
 
 template <int OP>
 static void run(const char* name, const unsigned* d_in, unsigned* d_out, unsigned long long* d_clk, int blocks) {
-    const int iters = 20000;
+    const int iters = 4000;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     hipLaunchKernelGGL((op_kernel<OP>), dim3(blocks), dim3(256), 0, 0, d_in, d_out, 200, d_clk);
@@ -49,7 +85,7 @@ static void run(const char* name, const unsigned* d_in, unsigned* d_out, unsigne
     CHECK(hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost));
     double ops = (double)blocks * 256 * 16 * iters;
     double ghz = (double)clk[0] / ((double)clk[1] / 100e6) / 1e9;
-    printf("%-16s blocks=%5d %.3f ms  %.2f Tlane-op/s  clock %.2f GHz  lane-ops/clk/CU %.1f\n", name, blocks, ms,
+    printf("%-18s blocks=%5d %.3f ms  %.2f Tlane-op/s  clock %.2f GHz  lane-ops/clk/CU %.1f\n", name, blocks, ms,
            ops / ms / 1e9, ghz, ops / (ms * 1e-3) / (ghz * 1e9) / 256.0);
 }
 
@@ -62,13 +98,47 @@ int main() {
     for (int bpc : {2, 8}) {
         int blocks = 256 * bpc;
         run<0>("v_xor_b32", d_in, d_out, d_clk, blocks);
-        run<1>("v_bcnt acc", d_in, d_out, d_clk, blocks);
-        run<6>("v_bcnt 0", d_in, d_out, d_clk, blocks);
+        run<1>("v_and_b32", d_in, d_out, d_clk, blocks);
         run<2>("v_add_u32", d_in, d_out, d_clk, blocks);
-        run<3>("v_min_u32", d_in, d_out, d_clk, blocks);
-        run<4>("v_lshl_or_b32", d_in, d_out, d_clk, blocks);
-        run<5>("v_min3_u32", d_in, d_out, d_clk, blocks);
-        run<7>("v_and_b32", d_in, d_out, d_clk, blocks);
+        run<3>("v_sub_u32", d_in, d_out, d_clk, blocks);
+        run<4>("v_min_u32", d_in, d_out, d_clk, blocks);
+        run<5>("v_max_i32", d_in, d_out, d_clk, blocks);
+        run<6>("v_min3_u32", d_in, d_out, d_clk, blocks);
+        run<7>("v_max3_i32", d_in, d_out, d_clk, blocks);
+        run<8>("v_med3_i32", d_in, d_out, d_clk, blocks);
+        run<9>("v_bcnt acc", d_in, d_out, d_clk, blocks);
+        run<10>("v_lshl_or_b32", d_in, d_out, d_clk, blocks);
+        run<11>("v_lshlrev_b32", d_in, d_out, d_clk, blocks);
+        run<12>("v_lshrrev_b32", d_in, d_out, d_clk, blocks);
+        run<13>("v_and_or_b32", d_in, d_out, d_clk, blocks);
+        run<14>("v_or3_b32", d_in, d_out, d_clk, blocks);
+        run<15>("v_add3_u32", d_in, d_out, d_clk, blocks);
+        run<16>("v_bfe_u32", d_in, d_out, d_clk, blocks);
+        run<17>("v_perm_b32", d_in, d_out, d_clk, blocks);
+        run<18>("v_alignbit_b32", d_in, d_out, d_clk, blocks);
+        run<19>("v_alignbyte_b32", d_in, d_out, d_clk, blocks);
+        run<20>("v_pk_add_u16", d_in, d_out, d_clk, blocks);
+        run<21>("v_pk_sub_i16", d_in, d_out, d_clk, blocks);
+        run<22>("v_pk_min_i16", d_in, d_out, d_clk, blocks);
+        run<23>("v_pk_max_i16", d_in, d_out, d_clk, blocks);
+        run<24>("v_pk_mul_lo_u16", d_in, d_out, d_clk, blocks);
+        run<25>("v_pk_mad_u16", d_in, d_out, d_clk, blocks);
+        run<26>("v_pk_lshrrev_b16", d_in, d_out, d_clk, blocks);
+        run<27>("v_mad_u32_u24", d_in, d_out, d_clk, blocks);
+        run<28>("v_mul_u32_u24", d_in, d_out, d_clk, blocks);
+        run<29>("v_mul_lo_u32", d_in, d_out, d_clk, blocks);
+        run<30>("v_dot4_u32_u8", d_in, d_out, d_clk, blocks);
+        run<31>("v_dot2_u32_u16", d_in, d_out, d_clk, blocks);
+        run<32>("v_sad_u8", d_in, d_out, d_clk, blocks);
+        run<33>("v_msad_u8", d_in, d_out, d_clk, blocks);
+        run<34>("v_cndmask_b32", d_in, d_out, d_clk, blocks);
+        run<35>("v_cmp+cndmask", d_in, d_out, d_clk, blocks);
+        run<36>("v_mbcnt_lo", d_in, d_out, d_clk, blocks);
+        run<37>("v_mov_b32 dpp", d_in, d_out, d_clk, blocks);
+        run<38>("v_add_f32", d_in, d_out, d_clk, blocks);
+        run<39>("v_fma_f32", d_in, d_out, d_clk, blocks);
+        run<40>("v_cvt_f32_u32", d_in, d_out, d_clk, blocks);
+        run<41>("v_cvt_f32_ubyte0", d_in, d_out, d_clk, blocks);
     }
     return 0;
 }
