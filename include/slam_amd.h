@@ -143,10 +143,10 @@ int slam_amd_extractor_debug_level(slam_amd_extractor* ex, int frame, int level,
                                    uint8_t* host_out, int host_stride);
 int slam_amd_extractor_debug_blurred_level(slam_amd_extractor* ex, int frame, int level,
                                            uint8_t* host_out, int host_stride);
-/* Corner survivors of an image row are collected in a fixed-size list (64
- * entries); a row with more is read back from the dense survivor map.  This
- * lowers the list size in use (0..64) so that tests can force that path. */
-int slam_amd_extractor_debug_set_row_list_capacity(slam_amd_extractor* ex, int entries);
+/* The selection step ranks the kept corners of a level from a cache of 4096 entries in LDS and
+ * falls back to ranking against the lists in memory when a level keeps more (long runs of equal
+ * scores).  This lowers the cache size in use (0..4096) so that tests can force that path. */
+int slam_amd_extractor_debug_set_select_cache(slam_amd_extractor* ex, int entries);
 
 /* ---- matching: replaces cv::BFMatcher::radiusMatch + _filterMatches ------
  * reference: slam::Matcher::frameMatch, src/frame/matcher.cpp:15-55 and

@@ -28,7 +28,7 @@ EXPORTS = [
     "slam_amd_default_orb_params",
     "slam_amd_extractor_create", "slam_amd_extractor_destroy", "slam_amd_extractor_levels", "slam_amd_extractor_set_grid",
     "slam_amd_extract", "slam_amd_extract_fetch", "slam_amd_extract_batch_async", "slam_amd_extractor_debug_level",
-    "slam_amd_extractor_debug_blurred_level", "slam_amd_extractor_debug_set_row_list_capacity",
+    "slam_amd_extractor_debug_blurred_level", "slam_amd_extractor_debug_set_select_cache",
     "slam_amd_matcher_create", "slam_amd_matcher_destroy", "slam_amd_matcher_reserve",
     "slam_amd_matcher_set_options", "slam_amd_matcher_debug_set_window_mode",
     "slam_amd_frame_match", "slam_amd_frame_match_async", "slam_amd_frame_match_noalloc_async",
@@ -109,7 +109,7 @@ def lib():
         l.slam_amd_extractor_set_grid.argtypes = [C.c_void_p, C.c_int]
         l.slam_amd_extractor_debug_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         l.slam_amd_extractor_debug_blurred_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
-        l.slam_amd_extractor_debug_set_row_list_capacity.argtypes = [C.c_void_p, C.c_int]
+        l.slam_amd_extractor_debug_set_select_cache.argtypes = [C.c_void_p, C.c_int]
         l.slam_amd_matcher_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         l.slam_amd_matcher_destroy.argtypes = [C.c_void_p]
         l.slam_amd_project_points.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
@@ -270,8 +270,8 @@ class Extractor:
                                                   _ptr(d_kp), _ptr(d_desc), _ptr(d_count), capacity,
                                                   C.c_void_p(stream)))
 
-    def debug_set_row_list_capacity(self, entries):
-        check(lib().slam_amd_extractor_debug_set_row_list_capacity(self._h, entries))
+    def debug_set_select_cache(self, entries):
+        check(lib().slam_amd_extractor_debug_set_select_cache(self._h, entries))
 
     def debug_level(self, frame, level, blurred=False):
         ws, hs, _, _ = self.levels()

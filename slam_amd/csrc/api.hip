@@ -101,7 +101,8 @@ struct slam_amd_extractor {
         size_t lds_bytes;
     };
     std::vector<PyrGroupPlan> pyr_groups;
-    DevBuf pyr, smap, blur, hist, rowlist, sel, kpxy;  // hist also holds the row fill counters
+    DevBuf pyr, blur, hist, tilecount, tilelist, sel, kpxy;
+    int select_keycap = 4096;          // kept survivors of a level ranked from LDS (debug knob)
     // host-call staging
     DevBuf h_img, h_kp, h_desc, h_count;
     int h_img_pitch = 0;
@@ -188,7 +189,6 @@ static int build_geometry_of(const slam_amd_orb_params& p, int width, int height
     g.frame_bytes = (off + 255u) & ~255u;
     g.total_rows = rows;
     g.total_tiles = tiles;
-    g.rowcap = kRowListCap;
     return SLAM_AMD_OK;
 }
 
@@ -391,12 +391,11 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
     const PyrGeom& g = ex->g;
     const size_t B = (size_t)max_batch;
     if ((rc = ex->pyr.reserve(B * g.frame_bytes))) return fail(rc);
-    if ((rc = ex->smap.reserve(B * g.frame_bytes))) return fail(rc);
     if ((rc = ex->blur.reserve(B * g.frame_bytes))) return fail(rc);
-    // histogram and row fill counters share one allocation: one memset clears both
     // (padded to 256 bytes: the per-call fill is rounded up to whole 256-byte blocks)
-    if ((rc = ex->hist.reserve(((B * ((size_t)g.nlevels * 256 + g.total_rows) * sizeof(unsigned)) + 255) & ~(size_t)255))) return fail(rc);
-    if ((rc = ex->rowlist.reserve(B * (size_t)g.total_rows * kRowListCap * sizeof(uint32_t)))) return fail(rc);
+    if ((rc = ex->hist.reserve(((B * (size_t)g.nlevels * 256 * sizeof(unsigned)) + 255) & ~(size_t)255))) return fail(rc);
+    if ((rc = ex->tilecount.reserve(B * (size_t)g.total_tiles * sizeof(unsigned)))) return fail(rc);
+    if ((rc = ex->tilelist.reserve(B * (size_t)g.total_tiles * kTileListCap * sizeof(uint32_t)))) return fail(rc);
     if ((rc = ex->sel.reserve(B * sizeof(FrameSelect)))) return fail(rc);
     if ((rc = ex->kpxy.reserve(B * (size_t)max_keypoints * sizeof(uint32_t)))) return fail(rc);
     // packed positions start out as zeros: a slot that was never written decodes to (0, 0, level 0),
@@ -416,7 +415,7 @@ extern "C" int slam_amd_extractor_destroy(slam_amd_extractor* ex) {
     if (!ex) return SLAM_AMD_OK;
     (void)hipSetDevice(ex->device);
     if (ex->stream) { (void)hipStreamSynchronize(ex->stream); (void)hipStreamDestroy(ex->stream); }
-    for (DevBuf* b : {&ex->tables, &ex->pyr, &ex->smap, &ex->blur, &ex->hist, &ex->rowlist, &ex->sel, &ex->kpxy,
+    for (DevBuf* b : {&ex->tables, &ex->pyr, &ex->blur, &ex->hist, &ex->tilecount, &ex->tilelist, &ex->sel, &ex->kpxy,
                       &ex->h_img, &ex->h_kp, &ex->h_desc, &ex->h_count})
         b->release();
     delete ex;
@@ -458,7 +457,7 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
 
     {
         ProfScope ps(kStageMemset, st);
-        const size_t bytes = (size_t)batch * ((size_t)g.nlevels * 256 + g.total_rows) * sizeof(unsigned);
+        const size_t bytes = (size_t)batch * (size_t)g.nlevels * 256 * sizeof(unsigned);
         SA_HIP(hipMemsetAsync(ex->hist.p, 0, (bytes + 255) & ~(size_t)255, st));
     }
     int rc;
@@ -477,14 +476,13 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     prof_mark(kStageResize, false, st);
     FastArgs fa;
     fa.img0 = d_images; fa.img0_frame_pitch = frame_pitch; fa.img0_pitch = row_stride; fa.img0_aligned = aligned;
-    fa.pyr = ex->pyr.as<uint8_t>(); fa.smap = ex->smap.as<uint8_t>(); fa.blur = ex->blur.as<uint8_t>(); fa.hist = ex->hist.as<unsigned>();
-    unsigned* rowfill = ex->hist.as<unsigned>() + (size_t)batch * g.nlevels * 256;
-    fa.rowfill = rowfill; fa.rowlist = ex->rowlist.as<uint32_t>(); fa.g = g;
+    fa.pyr = ex->pyr.as<uint8_t>(); fa.blur = ex->blur.as<uint8_t>(); fa.hist = ex->hist.as<unsigned>();
+    fa.tilecount = ex->tilecount.as<unsigned>(); fa.tilelist = ex->tilelist.as<uint32_t>(); fa.g = g;
     fa.grid_shift = ex->grid_shift; fa.tiles_all = 0; fa.tiles_per_xcd = 0;
     { ProfScope ps(kStageFast, st); if ((rc = launch_fast(fa, batch, st))) return rc; }
     SelectCompactArgs sc;
-    sc.hist = ex->hist.as<unsigned>(); sc.rowfill = rowfill; sc.rowlist = ex->rowlist.as<uint32_t>();
-    sc.smap = ex->smap.as<uint8_t>(); sc.sel = ex->sel.as<FrameSelect>(); sc.d_count = d_count;
+    sc.hist = ex->hist.as<unsigned>(); sc.tilecount = ex->tilecount.as<unsigned>(); sc.tilelist = ex->tilelist.as<uint32_t>();
+    sc.keycap = ex->select_keycap; sc.sel = ex->sel.as<FrameSelect>(); sc.d_count = d_count;
     sc.kp = d_kp; sc.kpxy = ex->kpxy.as<uint32_t>(); sc.capacity = capacity; sc.g = g;
     { ProfScope ps(kStageSelect, st); if ((rc = launch_select_compact(sc, batch, st))) return rc; }
     DescribeArgs da;
@@ -575,10 +573,10 @@ extern "C" int slam_amd_extractor_set_grid(slam_amd_extractor* ex, int cell) {
     return SLAM_AMD_OK;
 }
 
-extern "C" int slam_amd_extractor_debug_set_row_list_capacity(slam_amd_extractor* ex, int entries) {
+extern "C" int slam_amd_extractor_debug_set_select_cache(slam_amd_extractor* ex, int entries) {
     if (!ex) SA_FAIL(SLAM_AMD_ERR_ARG, "extractor is null");
-    if (entries < 0 || entries > kRowListCap) SA_FAIL(SLAM_AMD_ERR_ARG, "entries out of range");
-    ex->g.rowcap = entries;
+    if (entries < 0 || entries > 4096) SA_FAIL(SLAM_AMD_ERR_ARG, "entries out of range");
+    ex->select_keycap = entries;
     return SLAM_AMD_OK;
 }
 

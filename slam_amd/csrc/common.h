@@ -48,7 +48,6 @@ struct PyrGeom {
     int total_rows;     // sum of level heights
     int total_tiles;    // FAST tiles per frame
     unsigned frame_bytes;  // bytes of one frame's pyramid (and survivor map)
-    int rowcap;         // entries of a row's survivor list in use (<= kRowListCap)
     LevelGeom lv[kMaxLevels];
 };
 
@@ -73,11 +72,11 @@ struct ProfScope {
     ~ProfScope() { prof_mark(stage, false, st); }
 };
 
-// Survivor list of one image row: up to kRowListCap entries x | score << 16.
-constexpr int kRowListCap = 64;
-
 constexpr int kFastTileW = 64;
 constexpr int kFastTileH = 32;
+// Survivor list of one FAST tile.  A strict 3x3 maximum excludes its 8 neighbours, so a tile
+// holds at most one survivor per 2 x 2 block: the list cannot overflow.
+constexpr int kTileListCap = (kFastTileW / 2) * (kFastTileH / 2);
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 

@@ -41,6 +41,8 @@ constexpr int kScN = kScW * kScRows;                  // 2244 positions
 constexpr int kRowRows = kFastTileH + 6;              // 38 rows of the blur row pass
 constexpr int kListBytes = ((kScN * 2 + 15) / 16) * 16;
 
+__device__ __forceinline__ int div_up_dev(int a, int b) { return (a + b - 1) / b; }
+
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (n == 1) return 0;
     while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
@@ -114,8 +116,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     // lists (phases 1-3) and the blur row-pass buffer (phases 4-5) share one region
     __shared__ __align__(16) uint8_t s_scratch[2 * kListBytes];
     __shared__ unsigned s_hist[256];
-    __shared__ unsigned s_n[2];
+    __shared__ unsigned s_n[3];   // lengths of list 1, list 2 and the survivor list
     __shared__ unsigned s_cellbest[(kFastTileW / 8) * (kFastTileH / 8)];   // grid cells of >= 8 x 8 pixels
+    __shared__ uint32_t s_surv[kTileListCap];   // this tile's survivors: lx | ly << 6 | score << 16
     uint16_t* s_list1 = reinterpret_cast<uint16_t*>(s_scratch);
     uint16_t* s_list2 = reinterpret_cast<uint16_t*>(s_scratch + kListBytes);
     unsigned* s_row = reinterpret_cast<unsigned*>(s_scratch);  // [38][32] packed u16 pairs
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     }
     const int tid = threadIdx.x;
     s_hist[tid] = 0;
-    if (tid < 2) s_n[tid] = 0;
+    if (tid < 3) s_n[tid] = 0;
     if (tid < (kFastTileW / 8) * (kFastTileH / 8)) s_cellbest[tid] = 0;
     // Thread (column group cg, row rr) of an 18 x 14 arrangement: one dword column
     // of the staged tile, rows rr, rr + 14, rr + 28.  252 of the 256 threads take part.
@@ -295,39 +298,15 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     }
     lds_barrier();
     // ---- phase 4a: NMS + border filter, 4 pixels per thread ----
-    uint8_t* smap = a.smap + (size_t)b * a.g.frame_bytes + L.off;
-    if (!a.grid_shift) {
-        // the reference's selection: every NMS survivor inside the border goes on
-        const int tx = tid & 15, tr = tid >> 4;
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int ly = tr + 16 * rr;
-            const int gy = y0 + ly;
-            if (gy >= h) continue;
-            const uint8_t* q0 = s_sc + (ly + 1) * kScPitch + 4 + 4 * tx;
-            const uint32_t own = *reinterpret_cast<const uint32_t*>(q0);
-            uint32_t packed = 0;
-            if (own != 0 && level_ok && gy >= edge && gy < h - edge) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int s = (own >> (8 * j)) & 255;
-                    const int gx = x0 + 4 * tx + j;
-                    if (s == 0 || gx < edge || gx >= w - edge) continue;
-                    const uint8_t* q = q0 + j;
-                    if (s > q[-1] && s > q[1] && s > q[-kScPitch - 1] && s > q[-kScPitch] &&
-                        s > q[-kScPitch + 1] && s > q[kScPitch - 1] && s > q[kScPitch] && s > q[kScPitch + 1]) {
-                        packed |= (uint32_t)s << (8 * j);
-                        atomicAdd(&s_hist[s], 1u);
-                        const size_t row = (size_t)b * a.g.total_rows + L.row_base + gy;
-                        const unsigned slot = atomicAdd(&a.rowfill[row], 1u);
-                        if (slot < (unsigned)a.g.rowcap)
-                            a.rowlist[row * kRowListCap + slot] = (uint32_t)gx | ((uint32_t)s << 16);
-                    }
-                }
-            }
-            *reinterpret_cast<uint32_t*>(smap + (size_t)gy * L.pitch + x0 + 4 * tx) = packed;
-        }
-    } else {
+    // A strict 3x3 maximum has no second one among its 8 neighbours, so a 64 x 32 tile holds at
+    // most 32 x 16 = kTileListCap of them: the list cannot overflow.  Its order is arbitrary
+    // (the selection kernel ranks the kept entries by position).
+    auto keep_survivor = [&](int lx, int ly, unsigned sc) {
+        atomicAdd(&s_hist[sc], 1u);
+        const unsigned slot = atomicAdd(&s_n[2], 1u);
+        if (slot < (unsigned)kTileListCap) s_surv[slot] = (uint32_t)lx | ((uint32_t)ly << 6) | (sc << 16);
+    };
+    {
         const int tx = tid & 15, tr = tid >> 4;
         uint32_t keep[2] = {0u, 0u};   // NMS survivors of this thread's 4 pixels in rows tr and tr + 16
 #pragma unroll
@@ -352,11 +331,11 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             }
             keep[rr] = packed;
         }
-        // Optional grid distribution (not in the reference): of the survivors of one
-        // cell of grid_cell x grid_cell pixels only the best stays -- highest score,
-        // first in raster order among equals.  Cells are anchored at the level origin
-        // and divide the tile, so the contest is local to the workgroup.
-        {
+        if (a.grid_shift) {
+            // Optional grid distribution (not in the reference): of the survivors of one
+            // cell of grid_cell x grid_cell pixels only the best stays -- highest score,
+            // first in raster order among equals.  Cells are anchored at the level origin
+            // and divide the tile, so the contest is local to the workgroup.
             const int sh = a.grid_shift;
             auto contest = [&](bool write) {
 #pragma unroll
@@ -375,29 +354,17 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
                 }
             };
             contest(true);
-            lds_barrier();
+            lds_barrier();      // uniform: grid_shift is a kernel argument
             contest(false);
         }
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
-            const int ly = tr + 16 * rr;
-            const int gy = y0 + ly;
-            if (gy >= h) continue;
-            const uint32_t packed = keep[rr];
-            if (packed) {
+            if (!keep[rr]) continue;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const unsigned s = (packed >> (8 * j)) & 255u;
-                    if (s == 0) continue;
-                    const int gx = x0 + 4 * tx + j;
-                    atomicAdd(&s_hist[s], 1u);
-                    const size_t row = (size_t)b * a.g.total_rows + L.row_base + gy;
-                    const unsigned slot = atomicAdd(&a.rowfill[row], 1u);
-                    if (slot < (unsigned)a.g.rowcap)
-                        a.rowlist[row * kRowListCap + slot] = (uint32_t)gx | ((uint32_t)s << 16);
-                }
+            for (int j = 0; j < 4; j++) {
+                const unsigned s = (keep[rr] >> (8 * j)) & 255u;
+                if (s) keep_survivor(4 * tx + j, tr + 16 * rr, s);
             }
-            *reinterpret_cast<uint32_t*>(smap + (size_t)gy * L.pitch + x0 + 4 * tx) = packed;
         }
     }
     // ---- phase 4b: blur row pass, rows y0-3 .. y0+34, packed 16-bit arithmetic ----
@@ -447,6 +414,14 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             *reinterpret_cast<uint32_t*>(blur + (size_t)gy * L.pitch + x0 + 4 * cq) = packed;
         }
     }
+    // (the barrier after the blur row pass also completed the survivor list)
+    {
+        const unsigned ns = min(s_n[2], (unsigned)kTileListCap);
+        const size_t gt = (size_t)b * a.g.total_tiles + ftile;
+        if (tid == 0) a.tilecount[gt] = ns;
+        uint32_t* out = a.tilelist + gt * kTileListCap;
+        for (unsigned k = tid; k < ns; k += 256) out[k] = s_surv[k];
+    }
     const unsigned hv = s_hist[tid];
     if (hv) atomicAdd(&a.hist[((size_t)b * a.g.nlevels + l) * 256 + tid], hv);
 }
@@ -457,26 +432,27 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
 //      w (levels up to the workgroup's own), suffix sums over the 256 bins by
 //      shuffles -> cut score and kept count.  The level's first output index is
 //      the sum of the kept counts of the lower levels.
-//   2. One image row per thread: the survivors with score >= cut of the row's
-//      sparse list go to registers, the workgroup scans the counts, and every
-//      thread writes its keypoints in ascending x.  Rows in order and levels in
-//      order give the canonical (octave, y, x) order.
-// A row whose list overflowed is read from the dense survivor map instead.
+//   2. The kept survivors (score >= cut) of the level's tile lists are gathered into LDS as
+//      keys y << 14 | x, and every one is ranked by counting the smaller keys: its rank is its
+//      place in the canonical (octave, y, x) order.  The kept set of a level is about its quota
+//      (a few hundred to a few thousand keys), so the quadratic count is cheap, needs no sort
+//      and no atomics on the output.  A level with more kept survivors than the LDS cache
+//      holds (long runs of equal scores) is ranked against the tile lists in memory instead.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int level_of_row(const PyrGeom& g, int row) {
-    int l = 0;
-#pragma unroll 1
-    for (int i = 1; i < g.nlevels; i++)
-        if (row >= g.lv[i].row_base) l = i;
-    return l;
-}
+constexpr int kSelTileChunk = 4096;   // tiles whose counts are held in LDS at a time
+constexpr int kSelKeyCap = 4096;      // kept survivors ranked from LDS
 
 __global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs a) {
     __shared__ int s_cut[kMaxLevels], s_cnt[kMaxLevels];
-    __shared__ int s_wave[16];
+    __shared__ unsigned s_wave[16];
+    __shared__ unsigned s_pref[kSelTileChunk + 1];
+    __shared__ __align__(16) unsigned s_key[kSelKeyCap];
+    __shared__ uint8_t s_score[kSelKeyCap];
+    __shared__ unsigned s_n;
     const int b = blockIdx.x / a.g.nlevels;
     const int my_level = blockIdx.x - b * a.g.nlevels;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_n = 0;
     if (wave <= my_level) {
         const int l = wave;
         const unsigned* h = a.hist + ((size_t)b * a.g.nlevels + l) * 256;
@@ -514,109 +490,119 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs 
     }
     __syncthreads();
 
-    const int total_rows = a.g.total_rows, edge = a.g.edge;
-    const unsigned* fill = a.rowfill + (size_t)b * total_rows;
-    const uint32_t* lists = a.rowlist + (size_t)b * total_rows * kRowListCap;
-    const uint8_t* smap = a.smap + (size_t)b * a.g.frame_bytes;
-    slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity;
-    uint32_t* kpxy = a.kpxy + (size_t)b * a.capacity;
-    constexpr int kRegs = 16;             // list entries held in registers per row
-    constexpr unsigned kNone = 0xffffffffu;
     const int l = my_level;
     const LevelGeom& L = a.g.lv[l];
     const unsigned cut = (unsigned)s_cut[l];
-    int base = 0;                         // keypoints of lower levels and of earlier passes
+    const int kept = s_cnt[l];
+    int base = 0;                         // keypoints of the lower levels
     for (int i = 0; i < l; i++) base += s_cnt[i];
-    // One image row per thread and pass, rows inside the border only.
-    const int y_begin = edge, y_end = (cut < 256) ? L.h - edge : edge;
-    for (int y0 = y_begin; y0 < y_end; y0 += 1024) {
-        const int y = y0 + (int)threadIdx.x;
-        const int row = L.row_base + y;
-        unsigned n = 0;
-        if (y < y_end) n = fill[row];
-        const bool in_regs = n > 0 && n <= (unsigned)min(a.g.rowcap, kRegs);
-        const bool in_list = n > (unsigned)kRegs && n <= (unsigned)a.g.rowcap;
-        const bool dense = n > (unsigned)a.g.rowcap;
-        // sort key x << 8 | score of the kept entries; x is unique within a row
-        unsigned key[kRegs];
-        int cnt = 0;
-        if (in_regs) {
-            const uint32_t* e = lists + (size_t)row * kRowListCap;
+    slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity;
+    uint32_t* kpxy = a.kpxy + (size_t)b * a.capacity;
+    const int tiles_x = L.tiles_x, ntl = tiles_x * div_up_dev(L.h, kFastTileH);
+    const unsigned* tcount = a.tilecount + (size_t)b * a.g.total_tiles + L.tile_base;
+    const uint32_t* tlist = a.tilelist + ((size_t)b * a.g.total_tiles + L.tile_base) * kTileListCap;
+    const bool cached = kept <= a.keycap;   // uniform
+
+    auto emit = [&](unsigned key, unsigned sc, int rank) {
+        const int pos = base + rank;
+        if ((unsigned)pos < (unsigned)a.capacity) {
+            const unsigned x = key & 0x3fffu, y = key >> 14;
+            slam_amd_keypoint q;
+            q.x = (float)x;
+            q.y = (float)y;
+            q.size = L.size;
+            q.angle = -1.f;
+            q.response = (float)sc;
+            q.octave = l;
+            q.class_id = -1;
+            kp[pos] = q;
+            kpxy[pos] = x | (y << 14) | ((uint32_t)l << 28);
+        }
+    };
+    // key of entry e of tile t of this level
+    auto key_of = [&](int t, uint32_t e) -> unsigned {
+        const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+        const unsigned x = (unsigned)(txi * kFastTileW) + (e & 63u), y = (unsigned)(tyi * kFastTileH) + ((e >> 6) & 31u);
+        return (y << 14) | x;
+    };
+
+    if (kept > 0 && cut < 256) {
+        for (int chunk0 = 0; chunk0 < ntl; chunk0 += kSelTileChunk) {
+            const int nt = min(kSelTileChunk, ntl - chunk0);
+            // exclusive prefix of the tiles' survivor counts: four tiles per thread
+            unsigned c4[4], sum = 0;
 #pragma unroll
-            for (int i = 0; i < kRegs; i++) {
-                key[i] = kNone;
-                if ((unsigned)i < n) {
-                    const unsigned v = e[i], sc = v >> 16;
-                    if (sc >= cut) { key[i] = ((v & 0xffffu) << 8) | sc; cnt++; }
+            for (int k = 0; k < 4; k++) {
+                const int t = tid * 4 + k;
+                c4[k] = t < nt ? min(tcount[chunk0 + t], (unsigned)kTileListCap) : 0u;
+                sum += c4[k];
+            }
+            unsigned inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += v;
+            }
+            __syncthreads();              // s_pref / s_wave of the previous chunk have been read
+            if (lane == 63) s_wave[wave] = inc;
+            __syncthreads();
+            unsigned before = 0, total = 0;
+            for (int w = 0; w < 16; w++) {
+                const unsigned v = s_wave[w];
+                if (w < wave) before += v;
+                total += v;
+            }
+            unsigned run = before + inc - sum;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (tid * 4 + k < nt) s_pref[tid * 4 + k] = run;
+                run += c4[k];
+            }
+            if (tid == 0) s_pref[nt] = total;
+            __syncthreads();
+            // every entry of the chunk's lists, flat; its tile by binary search in the prefix
+            for (unsigned e = tid; e < total; e += 1024) {
+                int lo = 0, hi = nt;      // largest t with s_pref[t] <= e
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_pref[mid] <= e) lo = mid; else hi = mid;
+                }
+                const uint32_t ent = tlist[(size_t)(chunk0 + lo) * kTileListCap + (e - s_pref[lo])];
+                const unsigned sc = ent >> 16;
+                if (sc < cut) continue;
+                const unsigned key = key_of(chunk0 + lo, ent);
+                if (cached) {
+                    const unsigned slot = atomicAdd(&s_n, 1u);
+                    if (slot < (unsigned)kSelKeyCap) { s_key[slot] = key; s_score[slot] = (uint8_t)sc; }
+                } else {
+                    // rank against the lists in memory: every kept entry of the level with a smaller key
+                    int rank = 0;
+                    for (int t = 0; t < ntl; t++) {
+                        const unsigned n = min(tcount[t], (unsigned)kTileListCap);
+                        const uint32_t* p = tlist + (size_t)t * kTileListCap;
+                        for (unsigned j = 0; j < n; j++) {
+                            const uint32_t o = p[j];
+                            rank += ((o >> 16) >= cut) && (key_of(t, o) < key);
+                        }
+                    }
+                    emit(key, sc, rank);
                 }
             }
-        } else if (in_list) {
-            const uint32_t* e = lists + (size_t)row * kRowListCap;
-            for (unsigned i = 0; i < n; i++) cnt += (e[i] >> 16) >= cut;
-        } else if (dense) {
-            const uint8_t* r = smap + L.off + (size_t)y * L.pitch;
-            for (int x = edge; x < L.w - edge; x++) cnt += r[x] >= cut;
         }
-        // exclusive scan of the counts over the workgroup
-        int inc = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += v;
-        }
-        __syncthreads();                  // s_wave of the previous pass has been read
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        int pos = base + inc - cnt, pass_total = 0;
-        for (int w = 0; w < 16; w++) {
-            const int v = s_wave[w];
-            if (w < wave) pos += v;
-            pass_total += v;
-        }
-        base += pass_total;
-        if (cnt == 0) continue;
-        auto emit = [&](unsigned x, unsigned sc) {
-            if ((unsigned)pos < (unsigned)a.capacity) {
-                slam_amd_keypoint q;
-                q.x = (float)x;
-                q.y = (float)y;
-                q.size = L.size;
-                q.angle = -1.f;
-                q.response = (float)sc;
-                q.octave = l;
-                q.class_id = -1;
-                kp[pos] = q;
-                kpxy[pos] = x | ((uint32_t)y << 14) | ((uint32_t)l << 28);
-            }
-            pos++;
-        };
-        if (in_regs) {
-            // ascending x by repeated minimum over the register keys
-            for (int c = 0; c < cnt; c++) {
-                unsigned m = kNone;
-#pragma unroll
-                for (int i = 0; i < kRegs; i++) m = min(m, key[i]);
-#pragma unroll
-                for (int i = 0; i < kRegs; i++) if (key[i] == m) key[i] = kNone;
-                emit(m >> 8, m & 255u);
-            }
-        } else if (in_list) {
-            const uint32_t* e = lists + (size_t)row * kRowListCap;
-            int last = -1;
-            for (int c = 0; c < cnt; c++) {
-                unsigned bestx = kNone, bests = 0;
-                for (unsigned i = 0; i < n; i++) {
-                    const unsigned v = e[i], x = v & 0xffffu, sc = v >> 16;
-                    if (sc >= cut && (int)x > last && x < bestx) { bestx = x; bests = sc; }
+        if (cached) {
+            __syncthreads();
+            const int n = (int)min(s_n, (unsigned)kSelKeyCap);
+            // pad to a multiple of 4 with keys larger than any real one
+            if (tid < 4 && n + tid < kSelKeyCap) s_key[n + tid] = 0xffffffffu;
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024) {
+                const unsigned key = s_key[i];
+                int rank = 0;
+                for (int j = 0; j < n; j += 4) {
+                    const uint4 k4 = *reinterpret_cast<const uint4*>(&s_key[j]);
+                    rank += (k4.x < key) + (k4.y < key) + (k4.z < key) + (k4.w < key);
                 }
-                emit(bestx, bests);
-                last = (int)bestx;
-            }
-        } else {
-            const uint8_t* r = smap + L.off + (size_t)y * L.pitch;
-            for (int x = edge; x < L.w - edge; x++) {
-                const unsigned sc = r[x];
-                if (sc >= cut) emit((unsigned)x, sc);
+                emit(key, s_score[i], rank);
             }
         }
     }

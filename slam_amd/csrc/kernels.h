@@ -31,11 +31,10 @@ struct FastArgs {
     int img0_pitch;
     int img0_aligned;
     const uint8_t* pyr;   // levels >= 1 (level 0 slot unused)
-    uint8_t* smap;        // survivor map, same geometry as pyr (level 0 included)
     uint8_t* blur;        // blurred levels, same geometry as pyr (level 0 included)
     unsigned* hist;       // [batch][nlevels][256]
-    unsigned* rowfill;    // [batch][total_rows] survivors appended to each row's list
-    uint32_t* rowlist;    // [batch][total_rows][kRowListCap]
+    unsigned* tilecount;  // [batch][total_tiles] NMS survivors of every FAST tile
+    uint32_t* tilelist;   // [batch][total_tiles][kTileListCap] lx | ly << 6 | score << 16, any order
     int grid_shift;       // 0: off; 3, 4, 5: keep the best survivor of every 8, 16, 32 pixel cell
     int tiles_all;        // total_tiles * batch (set by the launcher)
     int tiles_per_xcd;    // ceil(tiles_all / 8)
@@ -44,9 +43,9 @@ struct FastArgs {
 
 struct SelectCompactArgs {
     const unsigned* hist;
-    const unsigned* rowfill;
-    const uint32_t* rowlist;
-    const uint8_t* smap;       // dense fallback for rows whose list overflowed
+    const unsigned* tilecount;
+    const uint32_t* tilelist;
+    int keycap;                // kept survivors of a level ranked from LDS (<= 4096; lower in tests)
     FrameSelect* sel;
     int32_t* d_count;          // may be null
     slam_amd_keypoint* kp;     // [batch][capacity]

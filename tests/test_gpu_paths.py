@@ -110,13 +110,13 @@ def test_extract_degenerate_images(oracle, capi):
     ex.close()
 
 
-def test_extract_row_list_overflow_falls_back_to_dense_rows(oracle, capi):
-    """Rows with more corner survivors than their sparse list holds take the dense path."""
+def test_extract_select_without_cache_ranks_from_memory(oracle, capi):
+    """Levels that keep more corners than the selection step's LDS cache holds are ranked from memory."""
     img = synth.scene(400, 300, 43)
     kp_o, d_o = oracle.detect_and_compute(oracle.params(nfeatures=800), img)
-    for entries in (0, 1, 2, 5, 64):
+    for entries in (0, 1, 100, 4096):
         ex = capi.Extractor(capi.orb_params(nfeatures=800), 400, 300, max_batch=1, max_keypoints=4096)
-        ex.debug_set_row_list_capacity(entries)
+        ex.debug_set_select_cache(entries)
         kp, d = ex.extract(img)
         ex.close()
         assert kp.tobytes() == kp_o.tobytes() and np.array_equal(d, d_o), entries
