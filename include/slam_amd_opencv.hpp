@@ -1,19 +1,21 @@
 // slam_amd_opencv.hpp -- drop-in slam::Detector and slam::Matcher for pxl-th/slam.
 //
-// Include this from the reference's include/frame/detector.hpp and
-// include/frame/matcher.hpp in place of their class bodies (or put it first on the
-// include path under those names).  The classes keep the reference's signatures,
-// default arguments and public members, so src/frame/frame.cpp, src/tracking/*.cpp
-// and main.cpp compile unchanged; src/frame/detector.cpp and src/frame/matcher.cpp
-// drop out of the build.  Needs OpenCV headers (core, features2d) and links
-// libslam_amd.so.
+// The classes keep the reference's signatures, default arguments and public members
+// (include/frame/detector.hpp:15-37, include/frame/matcher.hpp:15-117), so src/frame/frame.cpp,
+// src/tracking/*.cpp and main.cpp compile unchanged; src/frame/detector.cpp and
+// src/frame/matcher.cpp drop out of the build.  Needs OpenCV headers (core, features2d) and links
+// libslam_amd.so.  The two shims under include/dropin/frame/ carry the reference's file names and
+// include guards; INTEGRATION.md has the three CMake lines.
 //
-// Status: OpenCV is not installed where this library is built and tested, so this
-// header is compile-checked by nobody yet.  Everything it does beyond converting
-// types is in slam_amd.hpp, which is tested.
-#ifndef SLAM_AMD_OPENCV_HPP
-#define SLAM_AMD_OPENCV_HPP
+// slam::Matcher needs the complete slam::KeyFrame (include "map/keyframe.hpp" first, as the
+// reference's matcher.hpp does); define SLAM_AMD_OPENCV_DETECTOR_ONLY to get slam::Detector alone.
+//
+// Status: compiled and run in tests/cpp/test_dropin.cpp against a test-only stand-in of the
+// OpenCV types (OpenCV itself is not installed where this library is built).
+#ifndef SLAM_AMD_OPENCV_DETECTOR_HPP
+#define SLAM_AMD_OPENCV_DETECTOR_HPP
 
+#include <cstring>
 #include <map>
 #include <memory>
 #include <vector>
@@ -31,7 +33,7 @@ static_assert(sizeof(cv::DMatch) == sizeof(slam_amd::DMatch), "cv::DMatch layout
 // reference: include/frame/detector.hpp:15-37
 class Detector {
 private:
-    cv::Ptr<cv::ORB> detector;  // kept only as the carrier of the parameters
+    cv::Ptr<cv::ORB> detector;  // kept as the carrier of the parameters
     std::shared_ptr<slam_amd::Detector> gpu;
 public:
     Detector() {}
@@ -49,6 +51,7 @@ public:
         gpu = std::make_shared<slam_amd::Detector>(p);
     }
 
+    // reference: src/frame/detector.cpp:6-12
     void detect(std::shared_ptr<cv::Mat> image, std::vector<cv::KeyPoint>& keypoints,
                 std::shared_ptr<cv::Mat> descriptors) {
         CV_Assert(image->empty() || image->type() == CV_8UC1);
@@ -60,33 +63,29 @@ public:
         if (d.rows) std::memcpy(descriptors->data, d.bytes.data(), d.bytes.size());
     }
 
-    inline int getLevels() { return gpu->getLevels(); }
-    inline double getScaleFactor() { return gpu->getScaleFactor(); }
+    inline int getLevels() { return detector->getNLevels(); }
+    inline double getScaleFactor() { return detector->getScaleFactor(); }
 };
+
+}  // namespace slam
+
+#endif  // SLAM_AMD_OPENCV_DETECTOR_HPP
+
+#if !defined(SLAM_AMD_OPENCV_DETECTOR_ONLY) && !defined(SLAM_AMD_OPENCV_MATCHER_HPP)
+#define SLAM_AMD_OPENCV_MATCHER_HPP
+
+namespace slam {
 
 class KeyFrame;
-class MapPoint;
 
-// The one call the reference makes through Matcher::matcher directly
-// (src/tracking/mapper.cpp:336): match() of a 1 x 32 row against a 1 x 32 row.
-struct SinglePairMatcher {
-    void match(const cv::Mat& a, const cv::Mat& b, std::vector<cv::DMatch>& out) const {
-        out.clear();
-        if (a.empty() || b.empty()) return;
-        int d = 0;
-        for (int i = 0; i < 32; i++) d += __builtin_popcount(static_cast<unsigned>(a.data[i] ^ b.data[i]));
-        out.push_back(cv::DMatch(0, 0, 0, static_cast<float>(d)));
-    }
-};
-
-// reference: include/frame/matcher.hpp:15-117.  KF is slam::KeyFrame; it is a template
-// parameter only because matcher.hpp and keyframe.hpp include each other.
-template <class KF>
-class MatcherT {
+// reference: include/frame/matcher.hpp:15-117, src/frame/matcher.cpp
+class Matcher {
 public:
-    std::shared_ptr<SinglePairMatcher> matcher;
+    // The reference reaches through this member for its 1 x 32 against 1 x 32 duplicate test
+    // (src/tracking/mapper.cpp:336); that call stays OpenCV's.  Frame matching does not use it.
+    cv::Ptr<cv::BFMatcher> matcher;
 private:
-    std::shared_ptr<slam_amd::Matcher> gpu;
+    std::shared_ptr<slam_amd::Matcher> gpu;   // shared: Mapper and Tracker hold copies of one Matcher
 
     struct Packed {
         slam_amd::KeyFrameView view;
@@ -95,6 +94,7 @@ private:
         cv::Mat pose32;
         std::vector<double> dist;
     };
+    template <class KF>
     static void pack(const std::shared_ptr<KF>& kf, Packed& p, bool with_points) {
         const auto frame = kf->getFrame();
         p.view.descriptors = frame->descriptors->data;
@@ -111,15 +111,15 @@ private:
         p.view.mappointPositions = p.positions.empty() ? nullptr : p.positions.data();
         p.view.nMappoints = static_cast<int>(p.ids.size());
         kf->getPose().convertTo(p.pose32, CV_32F);
-        p.view.pose = p.pose32.ptr<float>();
+        p.view.pose = p.pose32.template ptr<float>();
         cv::Mat K;
         frame->cameraMatrix->convertTo(K, CV_64F);
-        p.view.fx = K.at<double>(0, 0); p.view.fy = K.at<double>(1, 1);
-        p.view.cx = K.at<double>(0, 2); p.view.cy = K.at<double>(1, 2);
+        p.view.fx = K.template at<double>(0, 0); p.view.fy = K.template at<double>(1, 1);
+        p.view.cx = K.template at<double>(0, 2); p.view.cy = K.template at<double>(1, 2);
         cv::Mat D;
         frame->distortions->convertTo(D, CV_64F);
         p.dist.assign(5, 0.0);
-        for (int i = 0; i < 5 && i < static_cast<int>(D.total()); i++) p.dist[i] = D.at<double>(i);
+        for (int i = 0; i < 5 && i < static_cast<int>(D.total()); i++) p.dist[i] = D.template at<double>(i);
         p.view.distortions = p.dist.data();
     }
     static std::vector<cv::DMatch> convert(const std::vector<slam_amd::DMatch>& in) {
@@ -128,37 +128,39 @@ private:
         return out;
     }
 public:
-    MatcherT() : matcher(std::make_shared<SinglePairMatcher>()), gpu(std::make_shared<slam_amd::Matcher>()) {}
+    // reference: include/frame/matcher.hpp:19 -- brute force, Hamming, crossCheck (which radiusMatch ignores)
+    Matcher() : matcher(cv::BFMatcher::create(cv::BFMatcher::BRUTEFORCE_HAMMING, true)),
+                gpu(std::make_shared<slam_amd::Matcher>()) {}
+    // reference: include/frame/matcher.hpp:20, src/frame/matcher.cpp:13
+    Matcher(cv::Ptr<cv::BFMatcher> matcher) : matcher(matcher), gpu(std::make_shared<slam_amd::Matcher>()) {}
 
-    std::vector<cv::DMatch> frameMatch(const std::shared_ptr<KF>& keyframe1, const std::shared_ptr<KF>& keyframe2,
+    std::vector<cv::DMatch> frameMatch(const std::shared_ptr<KeyFrame>& keyframe1, const std::shared_ptr<KeyFrame>& keyframe2,
                                        const std::vector<int>& ids, float maximumDistance = 300,
                                        float areaSize = -1, int maxLevel = 4) const {
         Packed a, b; pack(keyframe1, a, false); pack(keyframe2, b, false);
         return convert(gpu->frameMatch(a.view, b.view, ids, maximumDistance, areaSize, maxLevel));
     }
-    std::vector<cv::DMatch> mappointsFrameMatch(const std::shared_ptr<KF>& keyframe1,
-                                                const std::shared_ptr<KF>& keyframe2, float maximumDistance = 300,
+    std::vector<cv::DMatch> mappointsFrameMatch(const std::shared_ptr<KeyFrame>& keyframe1,
+                                                const std::shared_ptr<KeyFrame>& keyframe2, float maximumDistance = 300,
                                                 float areaSize = -1, int maxLevel = 4) const {
         Packed a, b; pack(keyframe1, a, false); pack(keyframe2, b, false);
         return convert(gpu->mappointsFrameMatch(a.view, b.view, maximumDistance, areaSize, maxLevel));
     }
-    std::vector<cv::DMatch> inverseMappointsFrameMatch(const std::shared_ptr<KF>& keyframe1,
-                                                       const std::shared_ptr<KF>& keyframe2,
+    std::vector<cv::DMatch> inverseMappointsFrameMatch(const std::shared_ptr<KeyFrame>& keyframe1,
+                                                       const std::shared_ptr<KeyFrame>& keyframe2,
                                                        float maximumDistance = 300, float areaSize = -1,
                                                        int maxLevel = 4) const {
         Packed a, b; pack(keyframe1, a, false); pack(keyframe2, b, false);
         return convert(gpu->inverseMappointsFrameMatch(a.view, b.view, maximumDistance, areaSize, maxLevel));
     }
-    std::vector<cv::DMatch> projectionMatch(const std::shared_ptr<KF>& fromKeyFrame,
-                                            const std::shared_ptr<KF>& toKeyFrame, float maximumDistance = 300,
+    std::vector<cv::DMatch> projectionMatch(const std::shared_ptr<KeyFrame>& fromKeyFrame,
+                                            const std::shared_ptr<KeyFrame>& toKeyFrame, float maximumDistance = 300,
                                             float areaSize = -1, int maxLevel = 4) const {
         Packed a, b; pack(fromKeyFrame, a, true); pack(toKeyFrame, b, false);
         return convert(gpu->projectionMatch(a.view, b.view, maximumDistance, areaSize, maxLevel));
     }
 };
 
-using Matcher = MatcherT<KeyFrame>;
-
 }  // namespace slam
 
-#endif
+#endif  // SLAM_AMD_OPENCV_MATCHER_HPP
