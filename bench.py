@@ -133,8 +133,8 @@ def launch_ranks(args, argv):
 
 
 class Ranks:
-    """Rank bookkeeping, the control-plane group (gloo: barriers, timing reductions) and,
-    when asked for, the RCCL group of the pair gather."""
+    """Rank bookkeeping and the control-plane group (gloo: barriers, timing reductions, handing the
+    RCCL unique id of the pair shard to the other ranks)."""
 
     def __init__(self, torch, dist, rehearse):
         self.torch, self.dist = torch, dist
@@ -142,7 +142,6 @@ class Ranks:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.rehearse = rehearse
-        self.data_group = None
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             # Control plane on gloo: the frame workload has no data-path collective, and a process
@@ -175,18 +174,10 @@ class Ranks:
         return [float(v) for v in t]
 
     def data_plane(self, dev):
-        """The group that moves result rows: RCCL on the GPUs (created after every graph has been
-        captured), the gloo group itself in a CPU rehearsal."""
-        if self.world == 1:
-            return None
-        if self.rehearse:
-            return self.dist.group.WORLD
-        if self.data_group is None:
-            try:
-                self.data_group = self.dist.new_group(backend="nccl", device_id=dev)
-            except TypeError:
-                self.data_group = self.dist.new_group(backend="nccl")
-        return self.data_group
+        """CPU rehearsal only: the group that carries the result rows there (gloo).  On the GPUs the
+        C++ pair shard owns its RCCL communicator; torch creates none, so no RCCL watchdog thread ever
+        runs beside a graph capture."""
+        return self.dist.group.WORLD if self.world > 1 else None
 
     def close(self):
         if self.world > 1:
@@ -454,7 +445,12 @@ def run_frames(args):
         guard = threading.Timer(args.pair_deadline, give_up)
         guard.daemon = True
         guard.start()
-        extra["pairs"] = run_pairs(args, torch, dist, capi, synth, m, dev, ranks, valu_peak)
+        try:
+            extra["pairs"] = run_pairs(args, torch, dist, capi, synth, m, dev, ranks, valu_peak)
+        except Exception as e:      # the frame line stands on its own
+            import traceback
+            traceback.print_exc()
+            extra["pairs"] = {"error": "%s: %s" % (type(e).__name__, e)}
         guard.cancel()
     ex.close(); m.close(); m_ratio.close()
     ranks.close()
@@ -551,7 +547,9 @@ def pmc_counters(kernel, batch, width, height):
 
 
 def run_pairs(args, torch, dist, capi, synth, m, dev, ranks, valu_peak):
-    """All i<j pairs of n_kf keyframes x n_per descriptors, gates off (the multi-GPU benchmark configuration)."""
+    """All i<j pairs of n_kf keyframes x n_per descriptors, gates off (the multi-GPU benchmark configuration).
+    Sharding, chunking and the gather to rank 0 are the C++ pair shard's (slam_amd_pair_shard_*, RCCL
+    send / recv on its own stream); torch only carries the RCCL unique id to the other ranks."""
     from slam_amd import pairs as pairs_mod
     world, rank = ranks.world, ranks.rank
     n_kf, n_per = args.pair_keyframes, args.pair_desc
@@ -559,19 +557,20 @@ def run_pairs(args, torch, dist, capi, synth, m, dev, ranks, valu_peak):
     d_desc = torch.from_numpy(desc).to(dev)
     pairs = pairs_mod.all_pairs(n_kf)
     n_pairs = len(pairs)
-    pg = pairs_mod.PairGather(torch, dist, n_pairs, n_per, world, rank, dev, args.pair_chunks,
-                              group=ranks.data_plane(dev))
-    d_pairs = torch.from_numpy(np.ascontiguousarray(pairs[pg.lo:max(pg.hi, pg.lo + 1)])).to(dev)
+    uid = None
+    if world > 1:
+        box = [capi.pair_shard_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    shard = capi.PairShard(m, ranks.local_rank, uid, world, rank, n_pairs, n_per, args.pair_chunks)
+    d_pairs = torch.from_numpy(np.ascontiguousarray(pairs[shard.lo:max(shard.hi, shard.lo + 1)])).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
-
-    def compute(a, b):
-        m.match_pairs_async(d_desc, None, n_kf, n_per, d_pairs.data_ptr() + a * 8, b - a,
-                            pg.res.data_ptr() + a * n_per * 4, 300.0, -1.0, -1, stream)
-
-    pg.run(compute, limit=64)  # warm-up on a few pairs per chunk, no gather
+    shard.run(d_desc, None, n_kf, d_pairs, 300.0, -1.0, -1, stream, limit_rows=64)   # warm-up: a few pairs per chunk, no exchange
+    shard.wait(stream)
     ranks.barrier()
     t0 = time.perf_counter()
-    pg.run(compute)
+    shard.run(d_desc, None, n_kf, d_pairs, 300.0, -1.0, -1, stream)
+    shard.wait(stream)
     ranks.barrier()
     dt = ranks.max_over_ranks([time.perf_counter() - t0])[0]
     total_cmp = float(n_pairs) * n_per * n_per
@@ -580,11 +579,16 @@ def run_pairs(args, torch, dist, capi, synth, m, dev, ranks, valu_peak):
            "gcmp_per_s": round(total_cmp / dt / 1e9, 1), "seconds": round(dt, 4), "n_gpus": world,
            "scaling": "strong", "valu_peak_gcmp_per_gpu": valu_peak,
            "valu_nominal_gcmp_per_gpu": VALU_NOMINAL_GCMP,
-           "valu_frac": round(total_cmp / dt / 1e9 / (valu_peak * world), 4)}
+           "valu_frac": round(total_cmp / dt / 1e9 / (valu_peak * world), 4),
+           "host": "C++ pair shard (slam_amd_pair_shard_*), RCCL send/recv in %d chunks" % args.pair_chunks}
     if rank == 0:
         # order-independent checksum of the gathered result, comparable across N
-        out = pg.result()
-        res["checksum"] = int(out.to(torch.int64).sum().item())
+        class _Table:   # the shard's device table as a torch tensor, without a copy
+            __cuda_array_interface__ = {"shape": (n_pairs, n_per), "typestr": "<i4", "data": (shard.result_ptr(), False),
+                                        "version": 2, "strides": None}
+        d_out = torch.as_tensor(_Table(), device=dev)
+        res["checksum"] = int(d_out.to(torch.int64).sum().item())
+    shard.close()
     return res
 
 

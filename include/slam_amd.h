@@ -328,6 +328,29 @@ int slam_amd_outlier_flags(slam_amd_matcher* m, const float* xyz, const slam_amd
                            const double* Rt_t, const double* K4_t, const double* dist5_t,
                            uint8_t* flags);
 
+/* ---- stream pipeline: frames in pinned host memory, copies overlapped with compute -------
+ * The reference processes its video one frame at a time on the host (main.cpp:110-140:
+ * read, cvtColor, resize, tracker.track).  This is that loop's extraction + frame-to-frame
+ * matching with the three transfers overlapped: upload of frame i + 1, extract + match of frame
+ * i against frame i - 1, download of frame i - 1's results, on three HIP streams over a ring of
+ * `depth` (>= 3) slots.  Frames are numbered 0, 1, 2, ... and submitted in order:
+ *   slam_amd_pipeline_input(p, i, &buf, &stride)  pinned host buffer to fill with frame i (blocks
+ *                                                 until the slot's previous occupant, frame i - depth, is done)
+ *   slam_amd_pipeline_submit(p, i)                enqueue everything for frame i, return at once
+ *   slam_amd_pipeline_result(p, i, ...)           wait for frame i; pointers into pinned host
+ *                                                 buffers, valid until _input(p, i + depth)
+ * Matches are frameMatch(frame i - 1, frame i, {}, max_dist, area, max_level): queries are the
+ * previous frame's keypoints (none for frame 0). */
+typedef struct slam_amd_pipeline slam_amd_pipeline;
+int slam_amd_pipeline_create(const slam_amd_orb_params* params, int width, int height, int capacity,
+                             int depth, int device, float max_dist, float area, int max_level,
+                             slam_amd_pipeline** out);
+int slam_amd_pipeline_destroy(slam_amd_pipeline* p);
+int slam_amd_pipeline_input(slam_amd_pipeline* p, long long frame, uint8_t** host_image, int* row_stride);
+int slam_amd_pipeline_submit(slam_amd_pipeline* p, long long frame);
+int slam_amd_pipeline_result(slam_amd_pipeline* p, long long frame, const slam_amd_keypoint** kp,
+                             const uint8_t** desc, int* n, const slam_amd_dmatch** matches, int* n_matches);
+
 /* ---- per-stage timing (process-wide, off by default) -------------------------
  * With max_marks > 0 every kernel stage launched through this library is
  * bracketed by HIP events on its own stream (up to max_marks stages recorded);

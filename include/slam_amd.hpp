@@ -396,6 +396,67 @@ private:
     slam_amd_matcher* m_ = nullptr;
 };
 
+// ---------------------------------------------------------------------------
+// FramePipeline: extraction + matching against the previous frame over a stream of frames in
+// host memory, with upload, compute and download overlapped (three HIP streams, a ring of
+// slots).  The reference's per-frame loop (main.cpp:110-140) without its serial copies.
+// ---------------------------------------------------------------------------
+class FramePipeline {
+public:
+    struct Result {
+        const KeyPoint* keypoints = nullptr;   // n records, pinned host memory of the slot
+        const uint8_t* descriptors = nullptr;  // n x 32
+        int n = 0;
+        const DMatch* matches = nullptr;       // frameMatch(previous frame, this frame): queryIdx = previous frame's keypoint
+        int nMatches = 0;
+    };
+    FramePipeline(const slam_amd_orb_params& params, int width, int height, int capacity, int depth = 3,
+                  float maximumDistance = 300, float areaSize = -1, int maxLevel = -1, int device = 0)
+        : width_(width), height_(height) {
+        check(slam_amd_pipeline_create(&params, width, height, capacity, depth, device, maximumDistance, areaSize,
+                                       maxLevel, &p_));
+    }
+    FramePipeline(const FramePipeline&) = delete;
+    FramePipeline& operator=(const FramePipeline&) = delete;
+    ~FramePipeline() { slam_amd_pipeline_destroy(p_); }
+
+    // Copies `image` (width x height, 8-bit grey) into the next slot and enqueues its processing.
+    // Returns the frame's index.  For zero-copy producers: input() + submit().
+    long long push(const Image8& image) {
+        if (image.cols != width_ || image.rows != height_) throw Error(SLAM_AMD_ERR_ARG, "frame size differs from the pipeline's");
+        int stride = 0;
+        uint8_t* dst = input(&stride);
+        for (int y = 0; y < height_; y++)
+            std::memcpy(dst + static_cast<size_t>(y) * static_cast<size_t>(stride), image.data + static_cast<size_t>(y) * image.step,
+                        static_cast<size_t>(width_));
+        return submit();
+    }
+    uint8_t* input(int* rowStride) {
+        uint8_t* buf = nullptr;
+        check(slam_amd_pipeline_input(p_, next_, &buf, rowStride));
+        return buf;
+    }
+    long long submit() {
+        check(slam_amd_pipeline_submit(p_, next_));
+        return next_++;
+    }
+    // Blocks until frame `index` is done.  The pointers stay valid until `depth` more frames were pushed.
+    Result result(long long index) const {
+        Result r;
+        const slam_amd_keypoint* kp = nullptr;
+        const slam_amd_dmatch* mt = nullptr;
+        check(slam_amd_pipeline_result(p_, index, &kp, &r.descriptors, &r.n, &mt, &r.nMatches));
+        r.keypoints = reinterpret_cast<const KeyPoint*>(kp);
+        r.matches = reinterpret_cast<const DMatch*>(mt);
+        return r;
+    }
+
+private:
+    slam_amd_pipeline* p_ = nullptr;
+    int width_, height_;
+    long long next_ = 0;
+};
+
 }  // namespace slam_amd
 
 #endif

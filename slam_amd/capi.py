@@ -38,6 +38,8 @@ EXPORTS = [
     "slam_amd_outlier_flags",
     "slam_amd_frontend_create", "slam_amd_frontend_destroy", "slam_amd_frontend_output_size",
     "slam_amd_frontend_run_async", "slam_amd_frontend_run", "slam_amd_linear_taps",
+    "slam_amd_pipeline_create", "slam_amd_pipeline_destroy", "slam_amd_pipeline_input", "slam_amd_pipeline_submit",
+    "slam_amd_pipeline_result",
     "slam_amd_prof_enable", "slam_amd_prof_collect", "slam_amd_prof_stage_name",
     "slam_amd_sincos_f32", "slam_amd_fast_atan2", "slam_amd_linear_exact_coeffs", "slam_amd_debug_pyramid_plan",
 ]
@@ -122,6 +124,84 @@ def lib():
         l.slam_amd_prof_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib = l
     return _lib
+
+
+DIST_LIB_PATH = os.path.join(_HERE, "libslam_amd_dist.so")
+DIST_EXPORTS = [
+    "slam_amd_pair_shard_range", "slam_amd_pair_shard_chunk", "slam_amd_pair_shard_unique_id",
+    "slam_amd_pair_shard_create", "slam_amd_pair_shard_destroy", "slam_amd_pair_shard_run",
+    "slam_amd_pair_shard_wait", "slam_amd_pair_shard_result",
+]
+UNIQUE_ID_BYTES = 128
+_dist = None
+
+
+def dist_lib():
+    """Load libslam_amd_dist.so (the pair shard over RCCL); the core library first."""
+    global _dist
+    if _dist is None:
+        lib()
+        if not os.path.exists(DIST_LIB_PATH):
+            raise OSError("%s not found: build it with `make -C slam_amd/csrc`" % DIST_LIB_PATH)
+        d = C.CDLL(DIST_LIB_PATH)
+        d.slam_amd_pair_shard_create.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.POINTER(C.c_void_p)]
+        d.slam_amd_pair_shard_destroy.argtypes = [C.c_void_p]
+        d.slam_amd_pair_shard_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                              C.c_float, C.c_float, C.c_int, C.c_void_p]
+        d.slam_amd_pair_shard_wait.argtypes = [C.c_void_p, C.c_void_p]
+        d.slam_amd_pair_shard_result.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        d.slam_amd_pair_shard_unique_id.argtypes = [C.c_char_p]
+        _dist = d
+    return _dist
+
+
+def pair_shard_range(n_pairs, world, rank):
+    lo, hi, per = C.c_int(0), C.c_int(0), C.c_int(0)
+    check(dist_lib().slam_amd_pair_shard_range(n_pairs, world, rank, C.byref(lo), C.byref(hi), C.byref(per)))
+    return lo.value, hi.value, per.value
+
+
+def pair_shard_chunk(per, chunks, chunk):
+    a, b = C.c_int(0), C.c_int(0)
+    check(dist_lib().slam_amd_pair_shard_chunk(per, chunks, chunk, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def pair_shard_unique_id():
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    check(dist_lib().slam_amd_pair_shard_unique_id(buf))
+    return buf.raw
+
+
+class PairShard:
+    """Owner of a slam_amd_pair_shard handle (keyframe-pair matching of one rank + gather to rank 0 over RCCL)."""
+
+    def __init__(self, matcher, device, unique_id, world, rank, n_pairs, n_per, chunks):
+        self._h = C.c_void_p()
+        self.world, self.rank, self.n_pairs, self.n_per = world, rank, n_pairs, n_per
+        self.lo, self.hi, self.per = pair_shard_range(n_pairs, world, rank)
+        check(dist_lib().slam_amd_pair_shard_create(matcher._h, device, unique_id, world, rank, n_pairs, n_per, chunks,
+                                                    C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            dist_lib().slam_amd_pair_shard_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def run(self, d_desc, d_kp, n_keyframes, d_pairs_local, max_dist=300.0, area=-1.0, max_level=-1, stream=0, limit_rows=-1):
+        check(dist_lib().slam_amd_pair_shard_run(self._h, _ptr(d_desc), _ptr(d_kp), n_keyframes, _ptr(d_pairs_local),
+                                                 int(limit_rows), max_dist, area, int(max_level), C.c_void_p(stream)))
+
+    def wait(self, stream=0):
+        check(dist_lib().slam_amd_pair_shard_wait(self._h, C.c_void_p(stream)))
+
+    def result_ptr(self):
+        """Rank 0: device address of the [n_pairs][n_per] uint32 table; other ranks: None."""
+        p = C.c_void_p()
+        n = C.c_int(0)
+        check(dist_lib().slam_amd_pair_shard_result(self._h, C.byref(p), C.byref(n)))
+        return p.value
 
 
 def check(status):

@@ -8,12 +8,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 EXE = os.path.join(HERE, "cpp", "test_host_layer")
 EXE_GRAPH = os.path.join(HERE, "cpp", "test_graph_capture")
 EXE_DROPIN = os.path.join(HERE, "cpp", "test_dropin")
+EXE_PIPE = os.path.join(HERE, "cpp", "test_pipeline_shard")
 
 
 def test_cpp_host_layer_builds():
     """CPU: the header-only C++ layer compiles with plain g++ and links the C ABI."""
     subprocess.check_call(["make", "-C", os.path.join(HERE, "cpp")], stdout=subprocess.DEVNULL)
-    assert os.path.exists(EXE) and os.path.exists(EXE_GRAPH) and os.path.exists(EXE_DROPIN)
+    assert os.path.exists(EXE) and os.path.exists(EXE_GRAPH) and os.path.exists(EXE_DROPIN) and os.path.exists(EXE_PIPE)
 
 
 def test_dropin_header_parses_against_the_reference_headers():
@@ -46,4 +47,13 @@ def test_cpp_dropin_opencv_header_call_shapes():
     stand-in of the OpenCV types) driven with the reference's call shapes, results vs the oracle."""
     assert os.path.exists(EXE_DROPIN), "build it first: make -C tests/cpp (or __graft_entry__.build())"
     r = subprocess.run([EXE_DROPIN], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_frame_pipeline_and_pair_shard():
+    """slam_amd::FramePipeline (three streams, pinned ring) against the sequential oracle, and
+    slam_amd::PairShard (the RCCL pair shard) with a world of one rank against the oracle."""
+    assert os.path.exists(EXE_PIPE), "build it first: make -C tests/cpp (or __graft_entry__.build())"
+    r = subprocess.run([EXE_PIPE], capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -148,3 +148,19 @@ def test_frontend_arguments_are_checked_before_touching_the_gpu(capi):
         capi.linear_taps(0, 10, 0.5, 1)
     with pytest.raises(capi.SlamAmdError):
         capi.linear_taps(10, 10, -1.0, 1)
+
+
+def test_dist_library_exports_and_share_arithmetic():
+    """libslam_amd_dist.so loads, exports what include/slam_amd_dist.h declares, and cuts the pair
+    list exactly as the Python driver of the same exchange (slam_amd/pairs.py) does."""
+    from slam_amd import capi, pairs
+    d = capi.dist_lib()
+    assert not [s for s in capi.DIST_EXPORTS if not hasattr(d, s)]
+    for n_pairs in (0, 1, 15, 523776):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                assert capi.pair_shard_range(n_pairs, world, rank) == pairs.shard(n_pairs, world, rank)
+            per = pairs.shard(n_pairs, world, 0)[2]
+            for chunks in (1, 4, 16):
+                for c in range(chunks):
+                    assert capi.pair_shard_chunk(per, chunks, c) == pairs.chunk_rows(per, chunks, c)
