@@ -17,7 +17,7 @@
 #endif
 
 static const int8_t k_pattern[256 * 4] = {
-#include "orb_pattern_31.inc"
+#include "../include/orb_pattern_31.inc"   /* the one copy of the table, shared with the library */
 };
 
 /* Disc of radius 15 used by the intensity centroid: half-width of row |v|. */

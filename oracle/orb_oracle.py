@@ -36,7 +36,7 @@ class Params(C.Structure):
 def build(force=False):
     """Compile the oracle with gcc if the shared library is missing or stale."""
     src = os.path.join(_HERE, "orb_oracle.c")
-    deps = [src, os.path.join(_HERE, "orb_oracle.h"), os.path.join(_HERE, "orb_pattern_31.inc")]
+    deps = [src, os.path.join(_HERE, "orb_oracle.h"), os.path.join(_HERE, "..", "include", "orb_pattern_31.inc")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(d) > os.path.getmtime(_LIB_PATH) for d in deps)
     if stale:

@@ -638,7 +638,7 @@ constexpr int kWaveLds = kURows * kUPitch + kBRows * kBPitch;  // 2596
 
 // rBRIEF sampling pattern as floats: x0, y0, x1, y1 of pair p at [4 * p].
 __constant__ __align__(16) float c_pattern[256 * 4] = {
-#include "orb_pattern_31.inc"
+#include "../../include/orb_pattern_31.inc"
 };
 
 // Half-width of row |v| of the radius-15 disc, 4 bits per row:

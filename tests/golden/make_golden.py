@@ -2,15 +2,16 @@
 """Regenerates the fixtures under tests/golden/ (run in the build container).
 
 chessboard_gray.npz   data/chessboard.png of the reference (its only image asset)
-                      converted to 8-bit grey with the fixed-point weights of
-                      cv::cvtColor(BGR2GRAY) used at main.cpp:124:
-                      (4899 R + 9617 G + 1868 B + 8192) >> 14.  Needs
-                      /root/reference and PIL; the fixture itself is data.
-chessboard_orb.npz    outputs of the CPU oracle on that image (resized to width
-                      1080 as main.cpp:18,125-129 does, here with the oracle's own
-                      bilinear resize) and on a homography warp of it, with the
-                      parameters of main.cpp:100, plus frameMatch(a, b, {}, 300,
-                      -1, 4) as at mapper.cpp:34.
+                      converted to 8-bit grey by the oracle's restatement of
+                      cv::cvtColor(BGR2GRAY) (main.cpp:124; the 15-bit weights
+                      (3735 B + 19235 G + 9798 R + 16384) >> 15 of OpenCV 4.x, the
+                      same the library's front end uses).  Needs /root/reference
+                      and PIL; the fixture itself is data.
+chessboard_orb.npz    outputs of the CPU oracle on that image, resized to width
+                      1080 as main.cpp:18,125-129 does (cv::resize INTER_LINEAR,
+                      the oracle's orc_resize_linear), and on a homography warp of
+                      it, with the parameters of main.cpp:100, plus
+                      frameMatch(a, b, {}, 300, -1, 4) as at mapper.cpp:34.
 
 The reference has no golden vectors and OpenCV is not installed, so these pin the
 oracle (and through it the GPU path) against regressions; they are not outputs of
@@ -31,9 +32,8 @@ def chessboard_pair():
     from slam_amd import synth
     gray = np.load(os.path.join(HERE, "chessboard_gray.npz"))["gray"]
     h, w = gray.shape
-    nw = 1080
-    nh = int(round(h * nw / w))
-    a = O.resize_linear_exact(gray, nw, nh)
+    a = O.resize_linear(gray, np.float32(1080) / np.float32(w))      # main.cpp:125-129
+    nh, nw = a.shape
     b = synth.warp(a, synth.homography(5.0, 12.0, -7.0, 1.03, nw / 2.0, nh / 2.0))
     return a, b
 
@@ -43,8 +43,9 @@ def main():
     out_gray = os.path.join(HERE, "chessboard_gray.npz")
     if os.path.exists(ref_png):
         from PIL import Image
-        im = np.asarray(Image.open(ref_png).convert("RGB")).astype(np.int64)
-        g = ((im[..., 0] * 4899 + im[..., 1] * 9617 + im[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+        from oracle import orb_oracle as O
+        rgb = np.asarray(Image.open(ref_png).convert("RGB"))
+        g = O.bgr2gray(np.ascontiguousarray(rgb[..., ::-1]))           # BGR order, as cv::imread delivers it
         np.savez_compressed(out_gray, gray=g)
     from oracle import orb_oracle as O
     a, b = chessboard_pair()

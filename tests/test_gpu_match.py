@@ -141,3 +141,23 @@ def test_cell_sorted_window_match_odd_positions(oracle, capi):
     got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=45.0, max_level=4)
     assert np.array_equal(got, oracle.match_gated_ex(d1, k1, d2, k2, 300.0, 45.0, 4, 0.9, 30))
     m.close()
+
+
+def test_match_10000_x_10000_vs_oracle(oracle, capi):
+    """The 4K stream configuration's matching size: 10 000 x 10 000 rows, gates off (brute force), with the
+    octave gate, and with the 50-pixel window (cell-sorted path), against the multi-threaded oracle."""
+    n = 10000
+    d2 = synth.random_descriptors(n, 31)
+    rng = np.random.default_rng(32)
+    src = rng.integers(0, n, size=n)
+    d1 = synth.noisy_copy(d2[src], 30, 33)
+    k1 = synth.random_keypoints(n, 3840, 2160, seed=34)
+    k2 = synth.random_keypoints(n, 3840, 2160, seed=35)
+    k1["x"] = k2["x"][src] + rng.normal(0, 25, n).astype(np.float32)
+    k1["y"] = k2["y"][src] + rng.normal(0, 25, n).astype(np.float32)
+    m = capi.Matcher()
+    for area, lvl in ((-1.0, -1), (-1.0, 4), (50.0, 4)):
+        got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=area, max_level=lvl)
+        ref = oracle.match_gated_mt(d1, k1, d2, k2, 300.0, area, lvl)
+        assert got.tobytes() == ref.tobytes() and len(got) > 5000, (area, lvl, len(got), len(ref))
+    m.close()
