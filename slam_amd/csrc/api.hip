@@ -603,6 +603,7 @@ struct slam_amd_matcher {
     bool baked = false;                // an _async call ran under stream capture: scratch pointers live in a graph
     unsigned char* static_scratch = nullptr;  // this device's copy of the file-scope scratch array (no-alloc entry point)
     int window_mode = 0;               // 0: choose by size, 1: always the full sweep, 2: always cell-sorted
+    int ungated_mode = 0;              // 0: matrix-core kernel when no gate and no ratio test is on, 1: always the VALU kernel
     float ratio = 0.f;                 // options beyond the reference, both off by default
     int histo_length = 0;
     DevBuf h_d1, h_k1, h_d2, h_k2, h_ids, h_xy, h_out, h_n, h_aux;  // host-call staging
@@ -712,6 +713,12 @@ extern "C" int slam_amd_matcher_reserve(slam_amd_matcher* m, int batch, int quer
 extern "C" int slam_amd_matcher_debug_set_window_mode(slam_amd_matcher* m, int mode) {
     if (!m || mode < 0 || mode > 2) SA_FAIL(SLAM_AMD_ERR_ARG, "mode must be 0, 1 or 2");
     m->window_mode = mode;
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_matcher_debug_set_ungated_mode(slam_amd_matcher* m, int mode) {
+    if (!m || mode < 0 || mode > 1) SA_FAIL(SLAM_AMD_ERR_ARG, "mode must be 0 or 1");
+    m->ungated_mode = mode;
     return SLAM_AMD_OK;
 }
 
@@ -825,7 +832,9 @@ static int match_common(slam_amd_matcher* m, int batch,
         a.part = second ? part_p : nullptr;
         a.part_pitch = rows;
         ProfScope ps(kStageMatch, st);
-        if ((rc = launch_match(a, plan, batch, st))) return rc;
+        if (!gated && !second && m->ungated_mode == 0) rc = launch_match_mfma(a, batch, nq, n2, m->n_cu, st);
+        else rc = launch_match(a, plan, batch, st);
+        if (rc) return rc;
     }
     FinalizeArgs f;
     memset(&f, 0, sizeof f);
@@ -953,6 +962,7 @@ extern "C" int slam_amd_match_pairs_async(slam_amd_matcher* m,
     a.area = area; a.max_level = max_level; a.dmax = dmax_of(max_dist);
     a.pairs = d_pairs; a.n_per = n_per; a.pair_out = d_out;
     ProfScope ps(kStageMatchPairs, reinterpret_cast<hipStream_t>(stream));
+    if (!gated && m->ungated_mode == 0) return launch_match_pairs_mfma(a, n_pairs, reinterpret_cast<hipStream_t>(stream));
     return launch_match_pairs(a, n_pairs, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -1,0 +1,228 @@
+// Brute-force Hamming matching on the matrix cores of gfx950 (gates off).
+//
+// All-pairs Hamming distance is a matrix product: with the 256 descriptor bits of a train row
+// as a 0/1 vector a and those of a query as b,
+//     H(a, b) = popcount(a) + popcount(b) - 2 a.b
+// v_mfma_i32_32x32x32_i8 forms a.b for a 32 x 32 block of (train, query) pairs; the train bits are
+// expanded to bytes {0, 1}, the query bits to bytes {0, -2}, and a ninth K-step adds popcount(a)
+// (the train side carries its per-dword popcounts, the query side ones), so that an accumulator
+// holds H - popcount(b) exactly.  popcount(b) is constant per query and is added after the
+// arg-min.  The running best is one signed minimum over (accumulator << 20) + train index, i.e.
+// the same key order as the VALU kernel: least distance, ties to the lowest train index.
+//
+// Layout of one product: train rows are the M side (A operand), queries the N side (B operand).
+// An accumulator register of lane l belongs to query l & 31, so the arg-min over the train rows
+// runs inside the lane; the two lane halves hold different train rows and are merged once at
+// the end.  Queries stay in registers for the whole kernel (expanded once); train tiles of 32
+// rows are expanded cooperatively into LDS, double buffered.
+//
+// The K order inside a step does not matter as long as both operands use the same one: lane
+// half h of either operand supplies the bits of bytes 16h .. 16h + 15 of its descriptor.
+#include "common.h"
+#include "kernels.h"
+
+namespace sa {
+
+constexpr int kMmBlock = 256;                 // 4 waves
+constexpr int kMmNB = 2;                      // query blocks of 32 per wave
+constexpr int kMmQueries = 4 * kMmNB * 32;    // queries per workgroup
+constexpr int kMmTile = 32;                   // train rows per tile
+constexpr int kMmSteps = 9;                   // 8 steps of 32 descriptor bits per lane half + the popcount step
+constexpr int kMmTileU4 = kMmSteps * 64;      // uint4 slots of one expanded tile: [step][half][row]
+constexpr unsigned kMmNoMatch = 0xffffffffu;
+constexpr int kMmIdxBits = 20;
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// 4 bits -> 4 bytes of 0 / 1 (bit j in byte j).
+__device__ __forceinline__ unsigned spread4(unsigned x4) { return (x4 * 0x00204081u) & 0x01010101u; }
+
+// 16 bits -> 16 bytes, each `scale` where the bit is set.
+__device__ __forceinline__ v4i expand16(unsigned bits16, unsigned scale) {
+    v4i r;
+    r.x = (int)(spread4(bits16 & 15u) * scale);
+    r.y = (int)(spread4((bits16 >> 4) & 15u) * scale);
+    r.z = (int)(spread4((bits16 >> 8) & 15u) * scale);
+    r.w = (int)(spread4(bits16 >> 12) * scale);
+    return r;
+}
+
+template <bool PAIRS>
+__global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
+    __shared__ uint4 s_tile[2][kMmTileU4];
+
+    int prob, qblock, split;
+    size_t qbase, tbase;
+    int nq, nt;
+    if (PAIRS) {
+        prob = blockIdx.x / a.qblocks;
+        qblock = blockIdx.x - prob * a.qblocks;
+        split = 0;
+        qbase = (size_t)a.pairs[2 * prob] * a.n_per;
+        tbase = (size_t)a.pairs[2 * prob + 1] * a.n_per;
+        nq = nt = a.n_per;
+    } else {
+        // 1-D grid, problem index fastest (see match_kernel)
+        const int id = blockIdx.x;
+        prob = id % a.batch;
+        const int rest = id / a.batch;
+        split = rest % a.splits;
+        qblock = rest / a.splits;
+        qbase = (size_t)prob * a.cap1;
+        tbase = (size_t)prob * a.cap2;
+        int n1 = a.n1, n2 = a.n2;
+        if (a.d_n1) n1 = min(n1, a.d_n1[prob]);
+        if (a.d_n2) n2 = min(n2, a.d_n2[prob]);
+        nq = a.ids ? a.n_ids : n1;
+        nt = n2;
+    }
+    const int t_begin = split * a.chunk;
+    const int t_end = PAIRS ? nt : min(nt, t_begin + a.chunk);
+    if (qblock * kMmQueries >= nq || t_begin >= t_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- queries of this wave: expanded once, {0, -2} bytes ----
+    v4i bq[kMmNB][8];
+    int pq[kMmNB];      // popcount of the whole query descriptor
+    int qidx[kMmNB];
+#pragma unroll
+    for (int b = 0; b < kMmNB; b++) {
+        const int qi = qblock * kMmQueries + (wave * kMmNB + b) * 32 + r;
+        qidx[b] = qi;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (qi < nq) {
+            const size_t row = qbase + (size_t)((!PAIRS && a.ids) ? a.ids[qi] : qi);
+            q = reinterpret_cast<const uint4*>(a.qdesc + row * 32)[h];
+        }
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+        int pc = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            pc += __builtin_popcount(w[d]);
+            bq[b][2 * d] = expand16(w[d] & 0xffffu, 0xfeu);
+            bq[b][2 * d + 1] = expand16(w[d] >> 16, 0xfeu);
+        }
+        pq[b] = pc + __shfl_xor(pc, 32, 64);
+    }
+    const v4i b_ones = {0x01010101, 0, 0, 0};   // picks the four per-dword popcounts of the train side
+
+    // ---- train tile staging: thread (d, tr) expands dword d of train row tr ----
+    const int sd = tid >> 5, tr = tid & 31;
+    const int sh = sd >> 2, sdd = sd & 3;
+    auto load_tile = [&](int t0) -> unsigned {
+        const int t = t0 + tr;
+        // rows beyond the set: all bits 0 and a popcount of 127 per dword, so that the row
+        // loses against every real one
+        return t < t_end ? reinterpret_cast<const unsigned*>(a.tdesc + (tbase + t) * 32)[sd] : 0u;
+    };
+    auto stage_tile = [&](int buf, int t0, unsigned w) {
+        const bool valid = t0 + tr < t_end;
+        uint4* dst = s_tile[buf];
+        const v4i lo = expand16(w & 0xffffu, 1u), hi = expand16(w >> 16, 1u);
+        dst[((2 * sdd) * 2 + sh) * 32 + tr] = make_uint4((unsigned)lo.x, (unsigned)lo.y, (unsigned)lo.z, (unsigned)lo.w);
+        dst[((2 * sdd + 1) * 2 + sh) * 32 + tr] = make_uint4((unsigned)hi.x, (unsigned)hi.y, (unsigned)hi.z, (unsigned)hi.w);
+        reinterpret_cast<uint8_t*>(dst + (8 * 2 + sh) * 32 + tr)[sdd] = (uint8_t)(valid ? __builtin_popcount(w) : 127);
+    };
+
+    // key offsets of the 16 accumulator registers: train row inside the tile, plus the tile's first row
+    int cvec[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) cvec[i] = t_begin + (i & 3) + 8 * (i >> 2) + 4 * h;
+    int best[kMmNB];
+#pragma unroll
+    for (int b = 0; b < kMmNB; b++) best[b] = 0x7fffffff;
+
+    // bytes 4 .. 15 of the popcount slots meet zeros of the query side; they only have to be defined
+    for (int i = tid; i < 2 * 64; i += kMmBlock) {
+        s_tile[0][8 * 64 + (i & 63)] = make_uint4(0u, 0u, 0u, 0u);
+        s_tile[1][8 * 64 + (i & 63)] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    lds_barrier();
+    stage_tile(0, t_begin, load_tile(t_begin));
+    lds_barrier();
+
+    int buf = 0;
+    for (int t0 = t_begin; t0 < t_end; t0 += kMmTile) {
+        const bool more = t0 + kMmTile < t_end;
+        unsigned wnext = 0;
+        if (more) wnext = load_tile(t0 + kMmTile);
+        v16i acc[kMmNB];
+#pragma unroll
+        for (int b = 0; b < kMmNB; b++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[b][i] = 0;
+        const uint4* tile = s_tile[buf];
+#pragma unroll
+        for (int s = 0; s < kMmSteps; s++) {
+            const uint4 t4 = tile[(s * 2 + h) * 32 + r];
+            const v4i af = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
+#pragma unroll
+            for (int b = 0; b < kMmNB; b++)
+                acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, s < 8 ? bq[b][s] : b_ones, acc[b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < kMmNB; b++) {
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const int k0 = __mul24(acc[b][i], 1 << kMmIdxBits) + cvec[i];
+                const int k1 = __mul24(acc[b][i + 1], 1 << kMmIdxBits) + cvec[i + 1];
+                best[b] = min(min(best[b], k0), k1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) cvec[i] += kMmTile;
+        if (more) stage_tile(buf ^ 1, t0 + kMmTile, wnext);
+        lds_barrier();
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int b = 0; b < kMmNB; b++) {
+        const int m = min(best[b], __shfl_xor(best[b], 32, 64));
+        if (h != 0 || qidx[b] >= nq) continue;
+        // m = (H - popcount(query)) << 20 | train; rows beyond the set carry distances above 256
+        const unsigned key = (unsigned)(m + (pq[b] << kMmIdxBits));
+        const unsigned d = key >> kMmIdxBits, t = key & ((1u << kMmIdxBits) - 1);
+        if (PAIRS) {
+            a.pair_out[(size_t)prob * a.n_per + qidx[b]] = (d <= 256u && (int)d <= a.dmax) ? ((d << 16) | t) : kMmNoMatch;
+        } else if (d <= 256u) {
+            atomicMin(&a.best[qbase + qidx[b]], key);
+        }
+    }
+}
+
+// Workgroups of 256 queries; the train set is split so that the grid fills the chip several
+// times over (capacities bound the grid, the true counts live on the device; workgroups beyond
+// them exit at once).  Splits are merged by atomicMin on the key.
+int launch_match_mfma(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st) {
+    if (nq_bound <= 0 || nt_bound <= 0 || batch <= 0) return SLAM_AMD_OK;
+    const int qblocks = div_up(nq_bound, kMmQueries);
+    int splits = div_up(n_cu * 6, qblocks * batch);
+    splits = std::max(1, std::min(splits, div_up(nt_bound, 8 * kMmTile)));
+    a.chunk = div_up(div_up(nt_bound, splits), kMmTile) * kMmTile;
+    a.splits = div_up(nt_bound, a.chunk);
+    a.qblocks = qblocks;
+    a.batch = batch;
+    const long long blocks = (long long)qblocks * a.splits * batch;
+    if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match: problem too large for one launch");
+    hipLaunchKernelGGL(match_mfma_kernel<false>, dim3((unsigned)blocks), dim3(kMmBlock), 0, st, a);
+    SA_HIP(hipGetLastError());
+    return SLAM_AMD_OK;
+}
+
+int launch_match_pairs_mfma(MatchArgs a, int n_pairs, hipStream_t st) {
+    if (n_pairs <= 0 || a.n_per <= 0) return SLAM_AMD_OK;
+    a.qblocks = div_up(a.n_per, kMmQueries);
+    a.chunk = 0;
+    a.splits = 1;
+    const long long blocks = (long long)a.qblocks * n_pairs;
+    if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match_pairs: too many pairs for one launch");
+    hipLaunchKernelGGL(match_mfma_kernel<true>, dim3((unsigned)blocks), dim3(kMmBlock), 0, st, a);
+    SA_HIP(hipGetLastError());
+    return SLAM_AMD_OK;
+}
+
+}  // namespace sa

@@ -161,3 +161,31 @@ def test_match_10000_x_10000_vs_oracle(oracle, capi):
         ref = oracle.match_gated_mt(d1, k1, d2, k2, 300.0, area, lvl)
         assert got.tobytes() == ref.tobytes() and len(got) > 5000, (area, lvl, len(got), len(ref))
     m.close()
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 33), (31, 32), (33, 31), (257, 64), (300, 1000), (2000, 2000), (513, 4097)])
+def test_matrix_core_match_equals_oracle_and_popcount_kernel(oracle, capi, nq, nt):
+    """Gates off: distances come from the i8 matrix-core product; ragged sizes around the 32-row
+    tiles and the 256-query workgroups, ties (duplicated train rows) and all-zero / all-one rows."""
+    d1, k1, d2, k2 = _sets(nq, nt, 71 + nq + nt)
+    if nt >= 8:
+        d2[3] = d2[5]            # equal distances: the lower train index must win
+        d2[nt - 1] = 0
+        d2[nt - 2] = 255
+    if nq >= 4:
+        d1[0] = 0
+        d1[1] = 255
+        d1[2] = d2[min(5, nt - 1)]
+    ref = oracle.match_gated(d1, k1, d2, k2, 300.0, -1.0, -1)
+    m = capi.Matcher()
+    got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=-1.0, max_level=-1)
+    m.debug_set_ungated_mode(1)
+    got_valu = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=-1.0, max_level=-1)
+    m.debug_set_ungated_mode(0)
+    ids = np.arange(nq - 1, -1, -2, dtype=np.int32)
+    got_ids = m.frame_match(d1, k1, d2, k2, ids=ids, max_dist=60.0, area=-1.0, max_level=-1)
+    ref_ids = oracle.frame_match(d1, k1, d2, k2, ids, 60.0, -1.0, -1)
+    m.close()
+    assert np.array_equal(got, ref)
+    assert np.array_equal(got_valu, ref)
+    assert np.array_equal(got_ids, ref_ids)

@@ -12,6 +12,10 @@ __global__ __launch_bounds__(256) void op_kernel(const unsigned* in, unsigned* o
     unsigned a[16];
     for (int i = 0; i < 16; i++) a[i] = in[(threadIdx.x + i * 7) & 1023];
     unsigned b = in[blockIdx.x & 1023];
+    const unsigned sb = __builtin_amdgcn_readfirstlane(b);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a2[8], b2 = {__uint_as_float(b), 1.0f};   // packed-f32 opcodes take register pairs
+    for (int i = 0; i < 8; i++) a2[i] = f2{__uint_as_float(a[2 * i]), __uint_as_float(a[2 * i + 1])};
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; it++) {
@@ -59,12 +63,53 @@ __global__ __launch_bounds__(256) void op_kernel(const unsigned* in, unsigned* o
             if (OP == 39) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
             if (OP == 40) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i]) :);
             if (OP == 41) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(a[i]) :);
+            if (OP == 42) asm volatile("v_or_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 43) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 44) asm volatile("v_not_b32 %0, %0" : "+v"(a[i]) :);
+            if (OP == 45) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(a[i]) :);
+            if (OP == 46) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 47) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 48) asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 49) asm volatile("v_max_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 50) asm volatile("v_min_i32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 51) asm volatile("v_max_f32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 52) asm volatile("v_min_f32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 53) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 54) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 55) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 56) asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 57) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a2[i & 7]) : "v"(b2));
+            if (OP == 58) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a2[i & 7]) : "v"(b2));
+            if (OP == 59) asm volatile("v_add_u16 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 60) asm volatile("v_sub_u16 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 61) asm volatile("v_max_u16 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 62) asm volatile("v_min_i16 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 63) asm volatile("v_mul_lo_u16 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 64) asm volatile("v_lshlrev_b16 %0, 1, %0" : "+v"(a[i]) :);
+            if (OP == 65) asm volatile("v_mul_i32_i24 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 66) asm volatile("v_mad_i32_i24 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 67) asm volatile("v_add_u32_e64 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 68) asm volatile("v_xor_b32_e64 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 69) asm volatile("v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(a[i]) : "v"(b));
+            if (OP == 70) asm volatile("v_and_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(a[i]) : "v"(b));
+            if (OP == 71) asm volatile("v_add_u32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b));
+            if (OP == 72) asm volatile("v_xor_b32 %0, 0x12345678, %0" : "+v"(a[i]) :);
+            if (OP == 73) asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "s"(sb));
+            if (OP == 74) asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+            if (OP == 75) asm volatile("v_cmp_gt_u32 vcc, %1, %0\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+            if (OP == 76) asm volatile("v_sub_u32 %0, %1, %0\n v_and_b32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+            if (OP == 77) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 78) asm volatile("v_xad_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 79) asm volatile("v_sad_u16 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 80) asm volatile("v_ffbl_b32 %0, %0" : "+v"(a[i]) :);
+            if (OP == 81) asm volatile("v_readfirstlane_b32 s20, %0" : : "v"(a[i]) : "s20");
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     unsigned r = 0;
     for (int i = 0; i < 16; i++) r ^= a[i];
+    for (int i = 0; i < 8; i++) r ^= __float_as_uint(a2[i].x) ^ __float_as_uint(a2[i].y);
     out[blockIdx.x * 256 + threadIdx.x] = r;
     if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
@@ -139,6 +184,46 @@ int main() {
         run<39>("v_fma_f32", d_in, d_out, d_clk, blocks);
         run<40>("v_cvt_f32_u32", d_in, d_out, d_clk, blocks);
         run<41>("v_cvt_f32_ubyte0", d_in, d_out, d_clk, blocks);
+        run<42>("v_or_b32", d_in, d_out, d_clk, blocks);
+        run<43>("v_mov_b32", d_in, d_out, d_clk, blocks);
+        run<44>("v_not_b32", d_in, d_out, d_clk, blocks);
+        run<45>("v_ashrrev_i32", d_in, d_out, d_clk, blocks);
+        run<46>("v_lshrrev_b32 v", d_in, d_out, d_clk, blocks);
+        run<47>("v_lshlrev_b32 v", d_in, d_out, d_clk, blocks);
+        run<48>("v_subrev_u32", d_in, d_out, d_clk, blocks);
+        run<49>("v_max_u32", d_in, d_out, d_clk, blocks);
+        run<50>("v_min_i32", d_in, d_out, d_clk, blocks);
+        run<51>("v_max_f32", d_in, d_out, d_clk, blocks);
+        run<52>("v_min_f32", d_in, d_out, d_clk, blocks);
+        run<53>("v_mul_f32", d_in, d_out, d_clk, blocks);
+        run<54>("v_sub_f32", d_in, d_out, d_clk, blocks);
+        run<55>("v_fmac_f32", d_in, d_out, d_clk, blocks);
+        run<56>("v_max3_f32", d_in, d_out, d_clk, blocks);
+        run<57>("v_pk_fma_f32", d_in, d_out, d_clk, blocks);
+        run<58>("v_pk_add_f32", d_in, d_out, d_clk, blocks);
+        run<59>("v_add_u16", d_in, d_out, d_clk, blocks);
+        run<60>("v_sub_u16", d_in, d_out, d_clk, blocks);
+        run<61>("v_max_u16", d_in, d_out, d_clk, blocks);
+        run<62>("v_min_i16", d_in, d_out, d_clk, blocks);
+        run<63>("v_mul_lo_u16", d_in, d_out, d_clk, blocks);
+        run<64>("v_lshlrev_b16", d_in, d_out, d_clk, blocks);
+        run<65>("v_mul_i32_i24", d_in, d_out, d_clk, blocks);
+        run<66>("v_mad_i32_i24", d_in, d_out, d_clk, blocks);
+        run<67>("v_add_u32 e64", d_in, d_out, d_clk, blocks);
+        run<68>("v_xor_b32 e64", d_in, d_out, d_clk, blocks);
+        run<69>("v_add_u32 sdwa", d_in, d_out, d_clk, blocks);
+        run<70>("v_and_b32 sdwa", d_in, d_out, d_clk, blocks);
+        run<71>("v_add_u32 dpp", d_in, d_out, d_clk, blocks);
+        run<72>("v_xor_b32 lit", d_in, d_out, d_clk, blocks);
+        run<73>("v_add_u32 sgpr", d_in, d_out, d_clk, blocks);
+        run<74>("v_cmp_gt_u32 vcc", d_in, d_out, d_clk, blocks);
+        run<75>("v_cmp+addc", d_in, d_out, d_clk, blocks);
+        run<76>("v_sub_u32 x2 + and", d_in, d_out, d_clk, blocks);
+        run<77>("v_bfi_b32", d_in, d_out, d_clk, blocks);
+        run<78>("v_xad_u32", d_in, d_out, d_clk, blocks);
+        run<79>("v_sad_u16", d_in, d_out, d_clk, blocks);
+        run<80>("v_ffbl_b32", d_in, d_out, d_clk, blocks);
+        run<81>("v_readfirstlane", d_in, d_out, d_clk, blocks);
     }
     return 0;
 }
