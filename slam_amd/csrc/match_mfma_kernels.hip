@@ -3,21 +3,27 @@
 // All-pairs Hamming distance is a matrix product: with the 256 descriptor bits of a train row
 // as a 0/1 vector a and those of a query as b,
 //     H(a, b) = popcount(a) + popcount(b) - 2 a.b
-// v_mfma_i32_32x32x32_i8 forms a.b for a 32 x 32 block of (train, query) pairs; the train bits are
-// expanded to bytes {0, 1}, the query bits to bytes {0, -2}, and a ninth K-step adds popcount(a)
-// (the train side carries its per-dword popcounts, the query side ones), so that an accumulator
-// holds H - popcount(b) exactly.  popcount(b) is constant per query and is added after the
-// arg-min.  The running best is one signed minimum over (accumulator << 20) + train index, i.e.
-// the same key order as the VALU kernel: least distance, ties to the lowest train index.
+// v_mfma_i32_32x32x32_i8 forms a.b for a 32 x 32 block of (train, query) pairs.  The train bits
+// are expanded to bytes {0, 1}, the query bits to bytes {0, -64}, and a ninth K-step adds
+// 32 popcount(a) + (row of the train inside its block of 32): the train side carries its four
+// per-dword popcounts and its row number, the query side 32, 32, 32, 32, 1.  An accumulator then
+// holds 32 (H - popcount(b)) + row exactly: the order of (distance, train index) inside the
+// block, so the arg-min over a block is a plain signed minimum over accumulators.  Across
+// blocks the running best is the minimum of (H - popcount(b)) << 20 | train index, rebuilt from
+// the block's minimum with three instructions.  popcount(b) is constant
+// per query and is added after the arg-min.  Ties go to the lowest train index, as in the
+// popcount kernel.
 //
 // Layout of one product: train rows are the M side (A operand), queries the N side (B operand).
 // An accumulator register of lane l belongs to query l & 31, so the arg-min over the train rows
 // runs inside the lane; the two lane halves hold different train rows and are merged once at
-// the end.  Queries stay in registers for the whole kernel (expanded once); train tiles of 32
+// the end.  Queries stay in registers for the whole kernel (expanded once); train tiles of 64
 // rows are expanded cooperatively into LDS, double buffered.
 //
 // The K order inside a step does not matter as long as both operands use the same one: lane
 // half h of either operand supplies the bits of bytes 16h .. 16h + 15 of its descriptor.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -26,11 +32,13 @@ namespace sa {
 constexpr int kMmBlock = 256;                 // 4 waves
 constexpr int kMmNB = 2;                      // query blocks of 32 per wave
 constexpr int kMmQueries = 4 * kMmNB * 32;    // queries per workgroup
-constexpr int kMmTile = 32;                   // train rows per tile
+constexpr int kMmSub = 32;                    // train rows of one product
+constexpr int kMmTile = 64;                   // train rows per LDS tile (two products)
 constexpr int kMmSteps = 9;                   // 8 steps of 32 descriptor bits per lane half + the popcount step
-constexpr int kMmTileU4 = kMmSteps * 64;      // uint4 slots of one expanded tile: [step][half][row]
+constexpr int kMmSubU4 = kMmSteps * 64;       // uint4 slots of one expanded block of 32 rows: [step][half][row]
 constexpr unsigned kMmNoMatch = 0xffffffffu;
 constexpr int kMmIdxBits = 20;
+constexpr int kMmBlockBits = 15;              // kMmIdxBits minus the 5 row bits an accumulator carries
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -50,7 +58,7 @@ __device__ __forceinline__ v4i expand16(unsigned bits16, unsigned scale) {
 
 template <bool PAIRS>
 __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
-    __shared__ uint4 s_tile[2][kMmTileU4];
+    __shared__ uint4 s_tile[2][2 * kMmSubU4];
 
     int prob, qblock, split;
     size_t qbase, tbase;
@@ -77,14 +85,14 @@ __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
         nq = a.ids ? a.n_ids : n1;
         nt = n2;
     }
-    const int t_begin = split * a.chunk;
+    const int t_begin = split * a.chunk;      // a multiple of kMmTile
     const int t_end = PAIRS ? nt : min(nt, t_begin + a.chunk);
     if (qblock * kMmQueries >= nq || t_begin >= t_end) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
-    // ---- queries of this wave: expanded once, {0, -2} bytes ----
+    // ---- queries of this wave: expanded once, {0, -64} bytes ----
     v4i bq[kMmNB][8];
     int pq[kMmNB];      // popcount of the whole query descriptor
     int qidx[kMmNB];
@@ -102,78 +110,94 @@ __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
 #pragma unroll
         for (int d = 0; d < 4; d++) {
             pc += __builtin_popcount(w[d]);
-            bq[b][2 * d] = expand16(w[d] & 0xffffu, 0xfeu);
-            bq[b][2 * d + 1] = expand16(w[d] >> 16, 0xfeu);
+            bq[b][2 * d] = expand16(w[d] & 0xffffu, 0xc0u);
+            bq[b][2 * d + 1] = expand16(w[d] >> 16, 0xc0u);
         }
         pq[b] = pc + __shfl_xor(pc, 32, 64);
     }
-    const v4i b_ones = {0x01010101, 0, 0, 0};   // picks the four per-dword popcounts of the train side
+    // ninth step, query side: 32 x the four per-dword popcounts of the train side, 1 x its row number.
+    // Both lane halves add their popcounts; only half 0 adds the row.
+    const v4i b_tail = {0x20202020, h == 0 ? 1 : 0, 0, 0};
 
-    // ---- train tile staging: thread (d, tr) expands dword d of train row tr ----
+    // ---- train tile staging: thread (d, tr) expands dword d of train rows tr and tr + 32 ----
     const int sd = tid >> 5, tr = tid & 31;
     const int sh = sd >> 2, sdd = sd & 3;
-    auto load_tile = [&](int t0) -> unsigned {
-        const int t = t0 + tr;
-        // rows beyond the set: all bits 0 and a popcount of 127 per dword, so that the row
-        // loses against every real one
-        return t < t_end ? reinterpret_cast<const unsigned*>(a.tdesc + (tbase + t) * 32)[sd] : 0u;
+    auto load_tile = [&](int t0, unsigned (&w)[2]) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int t = t0 + k * kMmSub + tr;
+            w[k] = t < t_end ? reinterpret_cast<const unsigned*>(a.tdesc + (tbase + t) * 32)[sd] : 0u;
+        }
     };
-    auto stage_tile = [&](int buf, int t0, unsigned w) {
-        const bool valid = t0 + tr < t_end;
-        uint4* dst = s_tile[buf];
-        const v4i lo = expand16(w & 0xffffu, 1u), hi = expand16(w >> 16, 1u);
-        dst[((2 * sdd) * 2 + sh) * 32 + tr] = make_uint4((unsigned)lo.x, (unsigned)lo.y, (unsigned)lo.z, (unsigned)lo.w);
-        dst[((2 * sdd + 1) * 2 + sh) * 32 + tr] = make_uint4((unsigned)hi.x, (unsigned)hi.y, (unsigned)hi.z, (unsigned)hi.w);
-        reinterpret_cast<uint8_t*>(dst + (8 * 2 + sh) * 32 + tr)[sdd] = (uint8_t)(valid ? __builtin_popcount(w) : 127);
+    auto stage_tile = [&](int buf, int t0, const unsigned (&w)[2]) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            // rows beyond the set: all bits 0 and a popcount of 127 per dword, so that the row
+            // loses against every real one
+            const bool valid = t0 + k * kMmSub + tr < t_end;
+            uint4* dst = s_tile[buf] + k * kMmSubU4;
+            const v4i lo = expand16(w[k] & 0xffffu, 1u), hi = expand16(w[k] >> 16, 1u);
+            dst[((2 * sdd) * 2 + sh) * 32 + tr] = make_uint4((unsigned)lo.x, (unsigned)lo.y, (unsigned)lo.z, (unsigned)lo.w);
+            dst[((2 * sdd + 1) * 2 + sh) * 32 + tr] = make_uint4((unsigned)hi.x, (unsigned)hi.y, (unsigned)hi.z, (unsigned)hi.w);
+            reinterpret_cast<uint8_t*>(dst + (8 * 2 + sh) * 32 + tr)[sdd] = (uint8_t)(valid ? __builtin_popcount(w[k]) : 127);
+        }
     };
 
-    // key offsets of the 16 accumulator registers: train row inside the tile, plus the tile's first row
-    int cvec[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) cvec[i] = t_begin + (i & 3) + 8 * (i >> 2) + 4 * h;
     int best[kMmNB];
 #pragma unroll
     for (int b = 0; b < kMmNB; b++) best[b] = 0x7fffffff;
 
-    // bytes 4 .. 15 of the popcount slots meet zeros of the query side; they only have to be defined
-    for (int i = tid; i < 2 * 64; i += kMmBlock) {
-        s_tile[0][8 * 64 + (i & 63)] = make_uint4(0u, 0u, 0u, 0u);
-        s_tile[1][8 * 64 + (i & 63)] = make_uint4(0u, 0u, 0u, 0u);
+    // ninth step, train side: bytes 0-3 per-dword popcounts (written per tile), byte 4 the row number,
+    // bytes 5-15 zero (they meet zeros of the query side; they only have to be defined)
+    if (tid < 128) {
+        const uint4 init = make_uint4(0u, (unsigned)(tid & 31), 0u, 0u);
+#pragma unroll
+        for (int bu = 0; bu < 2; bu++) {
+            s_tile[bu][8 * 64 + (tid & 63)] = init;            // rows 0-31 of the tile (tid & 63 = half * 32 + row)
+            s_tile[bu][kMmSubU4 + 8 * 64 + (tid & 63)] = init; // rows 32-63
+        }
     }
     lds_barrier();
-    stage_tile(0, t_begin, load_tile(t_begin));
+    {
+        unsigned w0[2];
+        load_tile(t_begin, w0);
+        stage_tile(0, t_begin, w0);
+    }
     lds_barrier();
 
     int buf = 0;
+    int blockno = 0;
     for (int t0 = t_begin; t0 < t_end; t0 += kMmTile) {
         const bool more = t0 + kMmTile < t_end;
-        unsigned wnext = 0;
-        if (more) wnext = load_tile(t0 + kMmTile);
-        v16i acc[kMmNB];
+        unsigned wnext[2] = {0u, 0u};
+        if (more) load_tile(t0 + kMmTile, wnext);
 #pragma unroll
-        for (int b = 0; b < kMmNB; b++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc[b][i] = 0;
-        const uint4* tile = s_tile[buf];
-#pragma unroll
-        for (int s = 0; s < kMmSteps; s++) {
-            const uint4 t4 = tile[(s * 2 + h) * 32 + r];
-            const v4i af = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
+        for (int k = 0; k < 2; k++) {
+            v16i acc[kMmNB];
 #pragma unroll
             for (int b = 0; b < kMmNB; b++)
-                acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, s < 8 ? bq[b][s] : b_ones, acc[b], 0, 0, 0);
-        }
 #pragma unroll
-        for (int b = 0; b < kMmNB; b++) {
+                for (int i = 0; i < 16; i++) acc[b][i] = 0;
+            const uint4* tile = s_tile[buf] + k * kMmSubU4;
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const int k0 = __mul24(acc[b][i], 1 << kMmIdxBits) + cvec[i];
-                const int k1 = __mul24(acc[b][i + 1], 1 << kMmIdxBits) + cvec[i + 1];
-                best[b] = min(min(best[b], k0), k1);
+            for (int s = 0; s < kMmSteps; s++) {
+                const uint4 t4 = tile[(s * 2 + h) * 32 + r];
+                const v4i af = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
+#pragma unroll
+                for (int b = 0; b < kMmNB; b++)
+                    acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, s < 8 ? bq[b][s] : b_tail, acc[b], 0, 0, 0);
             }
-        }
 #pragma unroll
-        for (int i = 0; i < 16; i++) cvec[i] += kMmTile;
+            for (int b = 0; b < kMmNB; b++) {
+                int m = acc[b][0];
+#pragma unroll
+                for (int i = 1; i < 16; i += 2) m = min(min(m, acc[b][i]), acc[b][i + 1 < 16 ? i + 1 : i]);
+                // 32 Hrel + row  ->  Hrel << 20 | block * 32 + row: order (distance, train index)
+                const int row = m & 31;
+                best[b] = min(best[b], m * (1 << kMmBlockBits) - row * ((1 << kMmBlockBits) - 1) + blockno);
+            }
+            blockno += kMmSub;
+        }
         if (more) stage_tile(buf ^ 1, t0 + kMmTile, wnext);
         lds_barrier();
         buf ^= 1;
@@ -183,13 +207,13 @@ __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
     for (int b = 0; b < kMmNB; b++) {
         const int m = min(best[b], __shfl_xor(best[b], 32, 64));
         if (h != 0 || qidx[b] >= nq) continue;
-        // m = (H - popcount(query)) << 20 | train; rows beyond the set carry distances above 256
-        const unsigned key = (unsigned)(m + (pq[b] << kMmIdxBits));
-        const unsigned d = key >> kMmIdxBits, t = key & ((1u << kMmIdxBits) - 1);
+        // m = (H - popcount(query)) << 20 | train row relative to t_begin; rows beyond the set carry distances above 256
+        const unsigned d = (unsigned)((m >> kMmIdxBits) + pq[b]);   // arithmetic shift: floor
+        const unsigned t = (unsigned)(t_begin + (m & ((1 << kMmIdxBits) - 1)));
         if (PAIRS) {
             a.pair_out[(size_t)prob * a.n_per + qidx[b]] = (d <= 256u && (int)d <= a.dmax) ? ((d << 16) | t) : kMmNoMatch;
         } else if (d <= 256u) {
-            atomicMin(&a.best[qbase + qidx[b]], key);
+            atomicMin(&a.best[qbase + qidx[b]], (d << kMmIdxBits) | t);
         }
     }
 }
@@ -201,7 +225,7 @@ int launch_match_mfma(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_
     if (nq_bound <= 0 || nt_bound <= 0 || batch <= 0) return SLAM_AMD_OK;
     const int qblocks = div_up(nq_bound, kMmQueries);
     int splits = div_up(n_cu * 6, qblocks * batch);
-    splits = std::max(1, std::min(splits, div_up(nt_bound, 8 * kMmTile)));
+    splits = std::max(1, std::min(splits, div_up(nt_bound, 4 * kMmTile)));
     a.chunk = div_up(div_up(nt_bound, splits), kMmTile) * kMmTile;
     a.splits = div_up(nt_bound, a.chunk);
     a.qblocks = qblocks;

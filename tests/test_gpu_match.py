@@ -176,7 +176,18 @@ def test_matrix_core_match_equals_oracle_and_popcount_kernel(oracle, capi, nq, n
         d1[0] = 0
         d1[1] = 255
         d1[2] = d2[min(5, nt - 1)]
+    if nt >= 128 and nq >= 8:
+        # equal rows in different 32-row blocks, the later one at a lower row of its block,
+        # and in different lane halves of one block
+        d2[66] = d2[37]
+        d2[97] = d2[37]
+        d2[12] = d2[9]
+        d1[5] = d2[37]
+        d1[6] = d2[9]
+        d1[7] = d2[97] ^ np.uint8(1)
     ref = oracle.match_gated(d1, k1, d2, k2, 300.0, -1.0, -1)
+    if nt >= 128 and nq >= 8:
+        assert ref[5]["trainIdx"] == 37 and ref[6]["trainIdx"] == 9 and ref[7]["trainIdx"] == 37
     m = capi.Matcher()
     got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=-1.0, max_level=-1)
     m.debug_set_ungated_mode(1)
