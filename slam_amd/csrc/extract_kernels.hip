@@ -17,29 +17,38 @@ namespace sa {
 
 // ---------------------------------------------------------------------------
 // FAST-9/16 + NMS + blur.  A workgroup owns a 64 x 32 tile of one level of one
-// frame.  The image tile with a 4-pixel halo is staged in LDS (reflect-101
-// outside the image), then
+// frame.  The image tile with a 4-pixel halo is staged in LDS twice (reflect-101
+// outside the image): as bytes, for the gathers of the sparse phases, and split
+// into even / odd columns with one pixel per 16-bit field, so that the dense
+// phases handle two pixels per 32-bit add / sub / and / or (the instructions that
+// issue at full rate on this chip; packed 16-bit and three-operand ones take twice
+// as long).  Then
 //   phase 1  every position of the tile plus a 1-pixel halo: compass test (a
-//            9-arc always covers two of the four compass points); survivors are
-//            compacted into an LDS list
-//   phase 2  full 16-pixel ring masks for the listed positions; corners are
+//            9-arc always holds one pixel of every opposite pair); the survivors
+//            are compacted into an LDS list, each with the polarity it can have
+//   phase 2  full 16-pixel ring for the listed positions, one polarity (brighter
+//            arcs are darker arcs of the complemented pixels); corners are
 //            compacted into a second list
-//   phase 3  corner score for the listed corners only
-//   phase 4  3x3 strict-maximum suppression + border filter -> survivor map,
-//            256-bin histogram of kept scores; 7-tap blur row pass (packed u16)
-//   phase 5  blur column pass -> blurred level
+//   phase 3  corner score for the listed corners, one polarity; meanwhile the
+//            vertical pass of the 7x7 blur runs on the split tile
+//   phase 4  3x3 strict-maximum suppression + border filter over the corner list
+//            -> survivor list and 256-bin score histogram; horizontal pass of
+//            the blur -> blurred level
 // The lists keep the expensive phases dense instead of divergent.
 // ---------------------------------------------------------------------------
 constexpr int kImgHalo = 4;
-constexpr int kImgPitch = kFastTileW + 2 * kImgHalo + 4;  // 72 staged columns; 19 dwords per row, odd, so that
-                                                          // the rows of a column fall into different LDS banks
+constexpr int kImgDw = (kFastTileW + 2 * kImgHalo) / 4;   // 18 staged dwords per row
+constexpr int kImgPitch = 4 * (kImgDw + 1);               // 76 bytes: 19 dwords per row, odd, so that the
+                                                          // rows of a column fall into different LDS banks
 constexpr int kImgRows = kFastTileH + 2 * kImgHalo;   // 40
+constexpr int kEoPitch = kImgDw + 2;                  // split tile: a zero entry on either side of the 18 groups
 constexpr int kScW = kFastTileW + 2;                  // 66 scored columns
 constexpr int kScRows = kFastTileH + 2;               // 34 scored rows
 constexpr int kScPitch = kImgPitch;                   // LDS column = tile column + 4
 constexpr int kScN = kScW * kScRows;                  // 2244 positions
-constexpr int kRowRows = kFastTileH + 6;              // 38 rows of the blur row pass
+constexpr int kScBytes = ((kScRows * kScPitch + 15) / 16) * 16;
 constexpr int kListBytes = ((kScN * 2 + 15) / 16) * 16;
+constexpr int kVPitch = 2 * kImgDw;                   // dwords per row of the vertical-pass result
 
 __device__ __forceinline__ int div_up_dev(int a, int b) { return (a + b - 1) / b; }
 
@@ -47,6 +56,13 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     if (n == 1) return 0;
     while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
     return i;
+}
+
+// reflect101 without a loop for n >= 4 and the indices a tile needs exactly (-4 <= i <= n + 3);
+// indices further out (staged but never used) are clamped into the image
+__device__ __forceinline__ int reflect101_near(int i, int n) {
+    int r = i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i);
+    return min(max(r, 0), n - 1);
 }
 
 __device__ __forceinline__ bool has_run9(unsigned m16) {
@@ -58,37 +74,18 @@ __device__ __forceinline__ bool has_run9(unsigned m16) {
     return (r & 0xffffu) != 0;
 }
 
-// v - ring[k] for the 16 ring pixels around c (LDS image tile, pitch kImgPitch).
-__device__ __forceinline__ void ring_diffs(const uint8_t* c, int (&d)[16]) {
-    const int P = kImgPitch;
-    const int v = c[0];
-    d[0] = v - c[3 * P];       d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
-    d[4] = v - c[3];           d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
-    d[8] = v - c[-3 * P];      d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
-    d[12] = v - c[-3];         d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
-}
+// x >> s, or x << -s for a negative (compile-time) s
+__device__ __forceinline__ unsigned shift_right(unsigned x, int s) { return s >= 0 ? x >> s : x << -s; }
 
-// Corner score: max(t, best arc of 9 by min |difference|) - 1.  Windows of 3 by
-// three-input min / max, windows of 9 from three windows of 3.
-__device__ __forceinline__ int fast_corner_score(const int (&d)[16], int t) {
-    int lo3[16], hi3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-        hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-    }
-    int a0 = t, b0 = 255;
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) {
-        const int lo9a = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
-        const int lo9b = min(min(lo3[k + 1], lo3[(k + 4) & 15]), lo3[(k + 7) & 15]);
-        const int hi9a = max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]);
-        const int hi9b = max(max(hi3[k + 1], hi3[(k + 4) & 15]), hi3[(k + 7) & 15]);
-        a0 = max(max(a0, lo9a), lo9b);
-        b0 = min(min(b0, hi9a), hi9b);
-    }
-    b0 = min(b0, -a0);
-    return -b0 - 1;
+// Inclusive prefix sum over the 64 lanes (DPP row shifts, then the row totals).
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
 }
 
 // Append the flagged lanes' values to an LDS list (order within the list is free).
@@ -103,27 +100,34 @@ __device__ __forceinline__ void list_append(bool flag, unsigned value, uint16_t*
 }
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-typedef short ss2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ ss2 as_ss2(unsigned v) { return __builtin_bit_cast(ss2, v); }
-__device__ __forceinline__ unsigned as_u32s(ss2 v) { return __builtin_bit_cast(unsigned, v); }
-
 __device__ __forceinline__ us2 as_us2(unsigned v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ unsigned as_u32(us2 v) { return __builtin_bit_cast(unsigned, v); }
 
+// a.lo * b.lo + a.hi * b.hi + c on 16-bit halves, saturating at 2^32 - 1
+__device__ __forceinline__ unsigned dot2(unsigned a, unsigned b, unsigned c) {
+    return __builtin_amdgcn_udot2(as_us2(a), as_us2(b), c, true);
+}
+
+// The ring of radius 3 as byte offsets in the staged tile, in circular order.
+#define SA_RING_OFFSETS(P) {3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1, \
+                            -3 * P, -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3, 2 * P - 2, 3 * P - 1}
+
 __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     __shared__ __align__(16) uint8_t s_img[kImgRows * kImgPitch];
-    __shared__ __align__(16) uint8_t s_sc[kScRows * kScPitch];
-    // lists (phases 1-3) and the blur row-pass buffer (phases 4-5) share one region
-    __shared__ __align__(16) uint8_t s_scratch[2 * kListBytes];
+    __shared__ __align__(16) uint2 s_eo[kImgRows * kEoPitch];       // {even, odd} columns of every staged dword
+    __shared__ __align__(16) uint8_t s_sc[kScBytes];
+    // list 1 (phases 1-2) and the vertical-pass result of the blur (phases 3-4) share one region
+    __shared__ __align__(16) uint8_t s_scratch[kFastTileH * kVPitch * 4];
+    __shared__ __align__(16) uint16_t s_list2[kListBytes / 2];
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_n[3];   // lengths of list 1, list 2 and the survivor list
     __shared__ unsigned s_cellbest[(kFastTileW / 8) * (kFastTileH / 8)];   // grid cells of >= 8 x 8 pixels
     __shared__ uint32_t s_surv[kTileListCap];   // this tile's survivors: lx | ly << 6 | score << 16
     uint16_t* s_list1 = reinterpret_cast<uint16_t*>(s_scratch);
-    uint16_t* s_list2 = reinterpret_cast<uint16_t*>(s_scratch + kListBytes);
-    unsigned* s_row = reinterpret_cast<unsigned*>(s_scratch);  // [38][32] packed u16 pairs
+    unsigned* s_v = reinterpret_cast<unsigned*>(s_scratch);   // [32][18] {even, odd} 16-bit column sums
     static_assert(kScPitch == kImgPitch, "score tile and image tile share one pitch");
-    static_assert(kRowRows * kFastTileW * 2 <= 2 * kListBytes, "row-pass buffer must fit the scratch region");
+    static_assert(kListBytes <= (int)sizeof(s_scratch), "list 1 must fit the scratch region");
+    constexpr int P = kImgPitch;
 
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  XCD k
     // takes the k-th contiguous eighth of all (frame, tile) pairs, so tiles that share
@@ -158,31 +162,42 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     s_hist[tid] = 0;
     if (tid < 3) s_n[tid] = 0;
     if (tid < (kFastTileW / 8) * (kFastTileH / 8)) s_cellbest[tid] = 0;
+    if (tid < kScBytes / 16) reinterpret_cast<uint4*>(s_sc)[tid] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 2 * kImgRows) s_eo[(tid >> 1) * kEoPitch + (tid & 1) * (kEoPitch - 1)] = make_uint2(0u, 0u);
     // Thread (column group cg, row rr) of an 18 x 14 arrangement: one dword column
     // of the staged tile, rows rr, rr + 14, rr + 28.  252 of the 256 threads take part.
-    const int rr = tid / 18, cg = tid - rr * 18;
-    const bool in_grid = tid < 252;
+    const int rr = tid / kImgDw, cg = tid - rr * kImgDw;
+    const bool in_grid = tid < kImgDw * 14;
     // ---- stage image tile + halo, reflect-101 outside the image ----
     if (in_grid) {
         const int gx = x0 - kImgHalo + 4 * cg;
         const bool fast = aligned && gx >= 0 && gx + 3 < w;
+        const bool near = w >= 4 && h >= 4;
         int rx[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) rx[j] = reflect101(gx + j, w);
+        for (int j = 0; j < 4; j++) rx[j] = near ? reflect101_near(gx + j, w) : reflect101(gx + j, w);
+        uint32_t v[3];
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            const int r = rr + 14 * it;
+            v[it] = 0;
+            if (r < kImgRows) {
+                const int gy = near ? reflect101_near(y0 - kImgHalo + r, h) : reflect101(y0 - kImgHalo + r, h);
+                const uint8_t* row = img + (size_t)gy * pitch;
+                if (fast) {
+                    v[it] = *reinterpret_cast<const uint32_t*>(row + gx);
+                } else {
+                    v[it] = (uint32_t)row[rx[0]] | ((uint32_t)row[rx[1]] << 8) | ((uint32_t)row[rx[2]] << 16) |
+                            ((uint32_t)row[rx[3]] << 24);
+                }
+            }
+        }
 #pragma unroll
         for (int it = 0; it < 3; it++) {
             const int r = rr + 14 * it;
             if (r < kImgRows) {
-                const int gy = reflect101(y0 - kImgHalo + r, h);
-                const uint8_t* row = img + (size_t)gy * pitch;
-                uint32_t v;
-                if (fast) {
-                    v = *reinterpret_cast<const uint32_t*>(row + gx);
-                } else {
-                    v = (uint32_t)row[rx[0]] | ((uint32_t)row[rx[1]] << 8) | ((uint32_t)row[rx[2]] << 16) |
-                        ((uint32_t)row[rx[3]] << 24);
-                }
-                *reinterpret_cast<uint32_t*>(s_img + r * kImgPitch + 4 * cg) = v;
+                *reinterpret_cast<uint32_t*>(s_img + r * P + 4 * cg) = v[it];
+                s_eo[r * kEoPitch + 1 + cg] = make_uint2(v[it] & 0x00ff00ffu, (v[it] >> 8) & 0x00ff00ffu);
             }
         }
     }
@@ -190,231 +205,241 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     const int t = a.g.fast_threshold;
     const int edge = a.g.edge;
     const bool level_ok = (w > 2 * edge) && (h > 2 * edge);
-    // ---- phase 1: compass test, 4 pixels per item, packed 16-bit arithmetic ----
-    // Item (row r of the scored region, column group cg) covers staged columns
-    // 4cg .. 4cg+3 of staged row r + 3.  With d = centre - compass pixel for the four
-    // compass points: an arc of 9 of the 16 ring pixels holds at least one pixel of every
-    // opposite pair, so a darker arc needs max(d0, d8) > t and max(d4, d12) > t, a brighter
-    // one min(d0, d8) < -t and min(d4, d12) < -t.
+    // ---- phase 1: compass test, two pixels per 32-bit operation ----
+    // Item (row r of the scored region, column group cg) covers staged columns 4cg .. 4cg+3 of
+    // staged row r + 3.  With d = centre - compass pixel for the four compass points: an arc of 9
+    // of the 16 ring pixels holds at least one pixel of every opposite pair, so a darker arc needs
+    // (d0 > t or d8 > t) and (d4 > t or d12 > t), a brighter one the same with d < -t.
+    // Fields are 16 bits wide and hold values below 1024, so sums and differences of fields never
+    // carry into the neighbouring field: centre + 512 - (t + 1) - x has bit 9 set exactly when
+    // centre - x > t, and x + 512 - (t + 1) - centre when x - centre > t.
     // Only positions that can matter are tested: a keypoint lies at least `edge` pixels from
     // the level border and its 3x3 suppression looks one pixel further, so scores outside
     // [edge - 1, size - edge] are never read (edge >= 31 > 3, the FAST margin).
+    {
+        // valid pixels of this thread's column group, in the layout of the flag word: pixel 0, 1 at
+        // bits 0, 1 (darker) and 2, 3 (brighter), pixels 2, 3 at bits 16 .. 19
+        unsigned cmask = 0;
+        if (in_grid && level_ok) {
 #pragma unroll
-    for (int it = 0; it < 3; it++) {
-        const int r = rr + 14 * it;
-        unsigned pass4 = 0;
-        if (in_grid && r < kScRows) {
-            const uint32_t* rowc = reinterpret_cast<const uint32_t*>(s_img + (r + 3) * kImgPitch);
-            const uint32_t C = rowc[cg];
-            const uint32_t Wm = cg > 0 ? rowc[cg - 1] : 0u;
-            const uint32_t Wp = cg < 17 ? rowc[cg + 1] : 0u;
-            const uint32_t U = reinterpret_cast<const uint32_t*>(s_img + r * kImgPitch)[cg];
-            const uint32_t D = reinterpret_cast<const uint32_t*>(s_img + (r + 6) * kImgPitch)[cg];
-            const uint32_t L = __builtin_amdgcn_alignbyte(C, Wm, 1);   // columns -3
-            const uint32_t R = __builtin_amdgcn_alignbyte(Wp, C, 3);   // columns +3
-            reinterpret_cast<uint32_t*>(s_sc)[r * (kScPitch / 4) + cg] = 0;  // clears the score tile
-            const ss2 T2 = {(short)t, (short)t};
-            unsigned f[2];
-#pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-                const unsigned sel = hf ? 0x0c030c02u : 0x0c010c00u;
-                const ss2 c = as_ss2(__builtin_amdgcn_perm(0u, C, sel));
-                const ss2 d0 = c - as_ss2(__builtin_amdgcn_perm(0u, D, sel));
-                const ss2 d4 = c - as_ss2(__builtin_amdgcn_perm(0u, R, sel));
-                const ss2 d8 = c - as_ss2(__builtin_amdgcn_perm(0u, U, sel));
-                const ss2 d12 = c - as_ss2(__builtin_amdgcn_perm(0u, L, sel));
-                const ss2 hi1 = __builtin_elementwise_max(d0, d8), lo1 = __builtin_elementwise_min(d0, d8);
-                const ss2 hi2 = __builtin_elementwise_max(d4, d12), lo2 = __builtin_elementwise_min(d4, d12);
-                // the smaller of the two pair maxima / the larger of the two pair minima
-                const ss2 dark = __builtin_elementwise_min(hi1, hi2), bright = __builtin_elementwise_max(lo1, lo2);
-                // sign bit of each 16-bit half set <=> that pixel passes
-                f[hf] = as_u32s(T2 - dark) | as_u32s(bright + T2);
+            for (int j = 0; j < 4; j++) {
+                const int sc = 4 * cg + j, gx = x0 - kImgHalo + sc;
+                if (sc >= 3 && sc <= kFastTileW + 4 && gx >= edge - 1 && gx < w - edge + 1)
+                    cmask |= 5u << ((j & 1) + 16 * (j >> 1));
             }
-            pass4 = ((f[0] >> 15) & 1u) | ((f[0] >> 30) & 2u) | ((f[1] >> 13) & 4u) | ((f[1] >> 28) & 8u);
-            // positions outside the scored region or within 3 pixels of the image edge
-            const int col0 = 4 * cg;                    // staged column of pixel 0
-            const int gx0 = x0 - kImgHalo + col0;
-            const int gy = y0 - 1 + r;
-            int jmin = max(3 - col0, (edge - 1) - gx0), jmax = min(69 - col0, (w - edge + 1) - gx0);
-            jmin = max(jmin, 0); jmax = min(jmax, 4);
-            unsigned vmask = (level_ok && jmax > jmin && gy >= edge - 1 && gy < h - edge + 1)
-                                 ? (((1u << jmax) - 1u) & ~((1u << jmin) - 1u)) : 0u;
-            pass4 &= vmask;
         }
-        // append the staged offsets of the passing pixels to list 1
-        const int lane = tid & 63;
-        const unsigned long long b0 = __ballot(pass4 & 1u), b1 = __ballot(pass4 & 2u),
-                                 b2 = __ballot(pass4 & 4u), b3 = __ballot(pass4 & 8u);
-        const int n0 = __builtin_popcountll(b0), n01 = n0 + __builtin_popcountll(b1),
-                  n012 = n01 + __builtin_popcountll(b2), total = n012 + __builtin_popcountll(b3);
+        const unsigned KB = 0x02000200u - (unsigned)(t + 1) * 0x00010001u;
+        unsigned Y = 0;   // flags of the thread's three items: item `it` shifted left by 4 it
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            const int r = rr + 14 * it;
+            const int gy = y0 - 1 + r;
+            if (r < kScRows) {      // uniform per wave except in the last one; the reads stay inside the tile
+                const uint2* rowc = s_eo + (r + 3) * kEoPitch + 1 + cg;
+                const uint2 W0 = rowc[-1], C = rowc[0], W2 = rowc[1];
+                const uint2 U = s_eo[r * kEoPitch + 1 + cg], D = s_eo[(r + 6) * kEoPitch + 1 + cg];
+                // even centres (pixels 0, 2): left = odd fields of the group before, right = pixels 3, 5
+                const unsigned RE = __builtin_amdgcn_alignbit(W2.y, C.y, 16);
+                // odd centres (pixels 1, 3): left = pixels -2, 0, right = even fields of the group after
+                const unsigned LO = __builtin_amdgcn_alignbit(C.x, W0.x, 16);
+                const unsigned klo_e = C.x + KB, khi_e = KB - C.x;
+                const unsigned klo_o = C.y + KB, khi_o = KB - C.y;
+                const unsigned dark_e = ((klo_e - U.x) | (klo_e - D.x)) & ((klo_e - W0.y) | (klo_e - RE));
+                const unsigned brig_e = ((U.x + khi_e) | (D.x + khi_e)) & ((W0.y + khi_e) | (RE + khi_e));
+                const unsigned dark_o = ((klo_o - U.y) | (klo_o - D.y)) & ((klo_o - LO) | (klo_o - W2.x));
+                const unsigned brig_o = ((U.y + khi_o) | (D.y + khi_o)) & ((LO + khi_o) | (W2.x + khi_o));
+                // bit 9 / 25 of each word -> bits 0 .. 3 / 16 .. 19, shifted left by 4 it
+                const unsigned y = (shift_right(dark_e, 9 - 4 * it) & (0x00010001u << (4 * it))) |
+                                   (shift_right(dark_o, 8 - 4 * it) & (0x00020002u << (4 * it))) |
+                                   (shift_right(brig_e, 7 - 4 * it) & (0x00040004u << (4 * it))) |
+                                   (shift_right(brig_o, 6 - 4 * it) & (0x00080008u << (4 * it)));
+                const bool row_ok = gy >= edge - 1 && gy < h - edge + 1;
+                Y |= y & (row_ok ? cmask << (4 * it) : 0u);
+            }
+        }
+        // one list entry per passing pixel: staged offset | darker << 12 | brighter << 14
+        unsigned E = (Y | (Y >> 2)) & 0x03330333u;
+        const int cnt = __builtin_popcount(E);
+        const int incl = wave_incl_scan(cnt);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total) {
             unsigned base = 0;
-            if (lane == 0) base = atomicAdd(&s_n[0], (unsigned)total);
-            base = __shfl(base, 0, 64);
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const unsigned code = (unsigned)((r + 3) * kImgPitch + 4 * cg);
-            if (pass4 & 1u) s_list1[base + __builtin_popcountll(b0 & lt)] = (uint16_t)code;
-            if (pass4 & 2u) s_list1[base + n0 + __builtin_popcountll(b1 & lt)] = (uint16_t)(code + 1);
-            if (pass4 & 4u) s_list1[base + n01 + __builtin_popcountll(b2 & lt)] = (uint16_t)(code + 2);
-            if (pass4 & 8u) s_list1[base + n012 + __builtin_popcountll(b3 & lt)] = (uint16_t)(code + 3);
+            if ((tid & 63) == 0) base = atomicAdd(&s_n[0], (unsigned)total);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            unsigned pos = base + (unsigned)(incl - cnt);
+            const unsigned code0 = (unsigned)((rr + 3) * P + 4 * cg);
+            while (E) {
+                const unsigned i = (unsigned)__builtin_ctz(E);
+                E &= E - 1;
+                // bit i: item (i & 15) >> 2, pixel 2 (i >> 4) + (i & 1)
+                const unsigned px = ((i >> 3) & 2u) | (i & 1u);
+                const unsigned code = code0 + (i & 12u) * (unsigned)(14 * P / 4) + px;
+                s_list1[pos++] = (uint16_t)(code | (((Y >> i) & 5u) << 12));
+            }
         }
     }
     lds_barrier();
-    // ---- phase 2: full ring, 9 contiguous darker or brighter ----
-    // One subtract and one funnel shift per flag: the sign of (ring - (v - t)) says
-    // "darker", the sign of ((v + t) - ring) "brighter"; alignbit shifts it into the mask.
+    // ---- phase 2: full ring, 9 contiguous darker (or, on complemented pixels, brighter) ----
+    // The sign of (ring - (v - t)) says "darker"; alignbit shifts it into the mask.
     const int n1 = (int)s_n[0];
     for (int k0 = 0; k0 < n1; k0 += 256) {
         const int k = k0 + tid;
         bool corner = false;
-        unsigned code = 0;
+        unsigned code = 0, pol = 0;
         if (k < n1) {
-            code = s_list1[k];
+            const unsigned e = s_list1[k];
+            code = e & 0xfffu;
             const uint8_t* p = s_img + code;
-            const int v = p[0];
-            const unsigned lo = (unsigned)(v - t), hi = (unsigned)(v + t);
-            unsigned dark = 0, bright = 0;
-            constexpr int P = kImgPitch;
-            constexpr int off[16] = {3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1,
-                                     -3 * P, -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3, 2 * P - 2, 3 * P - 1};
+            constexpr int off[16] = SA_RING_OFFSETS(P);
+            unsigned ring[16];
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const unsigned ring = p[off[j]];
-                dark = __builtin_amdgcn_alignbit(dark, ring - lo, 31);
-                bright = __builtin_amdgcn_alignbit(bright, hi - ring, 31);
+            for (int j = 0; j < 16; j++) ring[j] = p[off[j]];
+            const unsigned v = p[0];
+            auto arc = [&](unsigned x) {
+                const unsigned lo = (v ^ x) - (unsigned)t;
+                unsigned mask = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) mask = __builtin_amdgcn_alignbit(mask, (ring[j] ^ x) - lo, 31);
+                return has_run9(mask);
+            };
+            pol = (e >> 12) & 1u ? 0u : 1u;     // darker first where the compass test allows it
+            corner = arc(pol ? 0xffu : 0u);
+            if (!corner && (e & 0x5000u) == 0x5000u) {   // both polarities passed the compass test (rare)
+                pol = 1u;
+                corner = arc(0xffu);
             }
-            corner = has_run9(dark) || has_run9(bright);
         }
-        list_append(corner, code, s_list2, &s_n[1]);
+        list_append(corner, code | (pol << 12), s_list2, &s_n[1]);
     }
     lds_barrier();
-    // ---- phase 3: score of the corners ----
+    // ---- phase 3: score of the corners; vertical pass of the blur ----
+    // The score is the largest threshold that still detects: the best arc's smallest difference,
+    // minus one.  A darker corner has no brighter arc and vice versa, so one polarity suffices.
     const int n2 = (int)s_n[1];
     for (int k = tid; k < n2; k += 256) {
-        const unsigned code = s_list2[k];
+        const unsigned e = s_list2[k];
+        const unsigned code = e & 0xfffu, x = (e >> 12) ? 0xffu : 0u;
+        const uint8_t* p = s_img + code;
+        constexpr int off[16] = SA_RING_OFFSETS(P);
+        const int v = (int)(p[0] ^ x);
         int d[16];
-        ring_diffs(s_img + code, d);
-        s_sc[code - 3 * kImgPitch] = (uint8_t)fast_corner_score(d, t);   // same pitch, 3 rows up
+#pragma unroll
+        for (int j = 0; j < 16; j++) d[j] = v - (int)(p[off[j]] ^ x);
+        int lo3[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) lo3[j] = min(min(d[j], d[(j + 1) & 15]), d[(j + 2) & 15]);
+        int best = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            const int lo9a = min(min(lo3[j], lo3[(j + 3) & 15]), lo3[(j + 6) & 15]);
+            const int lo9b = min(min(lo3[j + 1], lo3[(j + 4) & 15]), lo3[(j + 7) & 15]);
+            best = max(max(best, lo9a), lo9b);
+        }
+        s_sc[code - 3 * P] = (uint8_t)(best - 1);   // same pitch, 3 rows up
+    }
+    // Blur, vertical pass: 7 taps 18 34 49 55 49 34 18 (8.8 fixed point, sum 256) down the
+    // columns of the split tile; the result fits 16 bits per pixel.  Item = (column group and
+    // parity, 4 output rows): 36 x 8 items.
+    for (int i = tid; i < 2 * kImgDw * (kFastTileH / 4); i += 256) {
+        const int chunk = i / (2 * kImgDw), cp = i - chunk * (2 * kImgDw);
+        const unsigned* src = reinterpret_cast<const unsigned*>(s_eo) + (4 * chunk + 1) * (2 * kEoPitch) + 2 + cp;
+        unsigned pcol[10];
+#pragma unroll
+        for (int j = 0; j < 10; j++) pcol[j] = src[j * 2 * kEoPitch];
+        const us2 k18 = {18, 18}, k34 = {34, 34}, k49 = {49, 49}, k55 = {55, 55};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const us2 s0 = as_us2(pcol[j] + pcol[j + 6]), s1 = as_us2(pcol[j + 1] + pcol[j + 5]),
+                      s2 = as_us2(pcol[j + 2] + pcol[j + 4]), s3 = as_us2(pcol[j + 3]);
+            s_v[(4 * chunk + j) * kVPitch + cp] = as_u32(s0 * k18 + s1 * k34 + s2 * k49 + s3 * k55);
+        }
     }
     lds_barrier();
-    // ---- phase 4a: NMS + border filter, 4 pixels per thread ----
+    // ---- phase 4a: NMS + border filter over the corner list ----
     // A strict 3x3 maximum has no second one among its 8 neighbours, so a 64 x 32 tile holds at
     // most 32 x 16 = kTileListCap of them: the list cannot overflow.  Its order is arbitrary
     // (the selection kernel ranks the kept entries by position).
-    auto keep_survivor = [&](int lx, int ly, unsigned sc) {
-        atomicAdd(&s_hist[sc], 1u);
-        const unsigned slot = atomicAdd(&s_n[2], 1u);
-        if (slot < (unsigned)kTileListCap) s_surv[slot] = (uint32_t)lx | ((uint32_t)ly << 6) | (sc << 16);
-    };
     {
-        const int tx = tid & 15, tr = tid >> 4;
-        uint32_t keep[2] = {0u, 0u};   // NMS survivors of this thread's 4 pixels in rows tr and tr + 16
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int ly = tr + 16 * rr;
-            const int gy = y0 + ly;
-            if (gy >= h) continue;
-            const uint8_t* q0 = s_sc + (ly + 1) * kScPitch + 4 + 4 * tx;
-            const uint32_t own = *reinterpret_cast<const uint32_t*>(q0);
-            uint32_t packed = 0;
-            if (own != 0 && level_ok && gy >= edge && gy < h - edge) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int s = (own >> (8 * j)) & 255;
-                    const int gx = x0 + 4 * tx + j;
-                    if (s == 0 || gx < edge || gx >= w - edge) continue;
-                    const uint8_t* q = q0 + j;
-                    if (s > q[-1] && s > q[1] && s > q[-kScPitch - 1] && s > q[-kScPitch] &&
-                        s > q[-kScPitch + 1] && s > q[kScPitch - 1] && s > q[kScPitch] && s > q[kScPitch + 1])
-                        packed |= (uint32_t)s << (8 * j);
-                }
+        const int sh = a.grid_shift;
+        // survivor of list entry k: lx | ly << 6 | score << 16, or 0
+        auto survivor = [&](int k) -> unsigned {
+            if (k >= n2) return 0u;
+            const unsigned code = s_list2[k] & 0xfffu;
+            const unsigned sr = (code * 1725u) >> 17;            // code / 76 for code < 4096
+            const int lx = (int)(code - sr * P) - kImgHalo, ly = (int)sr - kImgHalo;
+            const int gx = x0 + lx, gy = y0 + ly;
+            if ((unsigned)lx >= (unsigned)kFastTileW || (unsigned)ly >= (unsigned)kFastTileH || gx < edge ||
+                gx >= w - edge || gy < edge || gy >= h - edge)
+                return 0u;
+            const uint8_t* q = s_sc + code - 3 * P;
+            const int s = q[0];
+            if (s == 0) return 0u;
+            if (s > q[-1] && s > q[1] && s > q[-P - 1] && s > q[-P] && s > q[-P + 1] && s > q[P - 1] && s > q[P] &&
+                s > q[P + 1])
+                return (unsigned)lx | ((unsigned)ly << 6) | ((unsigned)s << 16);
+            return 0u;
+        };
+        // Optional grid distribution (not in the reference): of the survivors of one
+        // cell of grid_cell x grid_cell pixels only the best stays -- highest score,
+        // first in raster order among equals.  Cells are anchored at the level origin
+        // and divide the tile, so the contest is local to the workgroup.
+        auto cell_key = [&](unsigned sv, int& cell) -> unsigned {
+            const int lx = sv & 63, ly = (sv >> 6) & 31;
+            cell = (ly >> sh) * (kFastTileW >> sh) + (lx >> sh);
+            return (sv & 0xffff0000u) | (0xffffu - (unsigned)(ly * kFastTileW + lx));
+        };
+        if (sh) {
+            for (int k0 = 0; k0 < n2; k0 += 256) {
+                const unsigned sv = survivor(k0 + tid);
+                if (sv) { int cell; const unsigned key = cell_key(sv, cell); atomicMax(&s_cellbest[cell], key); }
             }
-            keep[rr] = packed;
-        }
-        if (a.grid_shift) {
-            // Optional grid distribution (not in the reference): of the survivors of one
-            // cell of grid_cell x grid_cell pixels only the best stays -- highest score,
-            // first in raster order among equals.  Cells are anchored at the level origin
-            // and divide the tile, so the contest is local to the workgroup.
-            const int sh = a.grid_shift;
-            auto contest = [&](bool write) {
-#pragma unroll
-                for (int rr = 0; rr < 2; rr++) {
-                    const int ly = tr + 16 * rr;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const unsigned s = (keep[rr] >> (8 * j)) & 255u;
-                        if (s == 0) continue;
-                        const int lx = 4 * tx + j;
-                        const int cell = (ly >> sh) * (kFastTileW >> sh) + (lx >> sh);
-                        const unsigned key = (s << 16) | (0xffffu - (unsigned)(ly * kFastTileW + lx));
-                        if (write) atomicMax(&s_cellbest[cell], key);
-                        else if (s_cellbest[cell] != key) keep[rr] &= ~(255u << (8 * j));
-                    }
-                }
-            };
-            contest(true);
             lds_barrier();      // uniform: grid_shift is a kernel argument
-            contest(false);
         }
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            if (!keep[rr]) continue;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const unsigned s = (keep[rr] >> (8 * j)) & 255u;
-                if (s) keep_survivor(4 * tx + j, tr + 16 * rr, s);
+        for (int k0 = 0; k0 < n2; k0 += 256) {
+            unsigned sv = survivor(k0 + tid);
+            if (sh && sv) { int cell; const unsigned key = cell_key(sv, cell); if (s_cellbest[cell] != key) sv = 0; }
+            const unsigned long long m = __ballot(sv != 0);
+            if (m) {
+                const int lane = tid & 63;
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&s_n[2], (unsigned)__builtin_popcountll(m));
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (sv) {
+                    atomicAdd(&s_hist[sv >> 16], 1u);
+                    const unsigned slot = base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    if (slot < (unsigned)kTileListCap) s_surv[slot] = sv;
+                }
             }
         }
     }
-    // ---- phase 4b: blur row pass, rows y0-3 .. y0+34, packed 16-bit arithmetic ----
-    // (the lists are dead: every thread passed the barrier after phase 3)
-    for (int it = tid; it < kRowRows * 16; it += 256) {
-        const int r = it >> 4, g = it & 15;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(s_img + (r + 1) * kImgPitch) + g;
-        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];  // bytes 4g .. 4g+11; tap p_k = byte k+1
-        // P_k = (p_k, p_k+1) as two 16-bit lanes
-        const us2 P0 = as_us2(__builtin_amdgcn_perm(w1, w0, 0x0c020c01));
-        const us2 P1 = as_us2(__builtin_amdgcn_perm(w1, w0, 0x0c030c02));
-        const us2 P2 = as_us2(__builtin_amdgcn_perm(w1, w0, 0x0c040c03));
-        const us2 P3 = as_us2(__builtin_amdgcn_perm(w1, w0, 0x0c050c04));
-        const us2 P4 = as_us2(__builtin_amdgcn_perm(w1, w0, 0x0c060c05));
-        const us2 P5 = as_us2(__builtin_amdgcn_perm(w1, w0, 0x0c070c06));
-        const us2 P6 = as_us2(__builtin_amdgcn_perm(w2, w1, 0x0c040c03));
-        const us2 P7 = as_us2(__builtin_amdgcn_perm(w2, w1, 0x0c050c04));
-        const us2 P8 = as_us2(__builtin_amdgcn_perm(w2, w1, 0x0c060c05));
-        const us2 k18 = {18, 18}, k34 = {34, 34}, k49 = {49, 49}, k55 = {55, 55};
-        const us2 o01 = (P0 + P6) * k18 + (P1 + P5) * k34 + (P2 + P4) * k49 + P3 * k55;
-        const us2 o23 = (P2 + P8) * k18 + (P3 + P7) * k34 + (P4 + P6) * k49 + P5 * k55;
-        s_row[r * 32 + 2 * g] = as_u32(o01);
-        s_row[r * 32 + 2 * g + 1] = as_u32(o23);
-    }
-    lds_barrier();
-    // ---- phase 5: blur column pass, 2 rows x 4 columns per thread ----
+    // ---- phase 4b: blur, horizontal pass: 4 pixels of one row per item, rows ly and ly + 16 ----
+    // The column sums sit in 16-bit halves, {columns 4g, 4g + 2} and {4g + 1, 4g + 3} per group, so
+    // every tap pair is one 16-bit dot product; min((sum + 2^15) >> 16, 255) is byte 2 of the accumulator:
+    // the taps add up to 257, so a sum can pass 2^24; the accumulator starts at 0xff000000 + 2^15
+    // and the dot products saturate, which turns exactly those sums into 0xffffffff.
     {
         uint8_t* blur = a.blur + (size_t)b * a.g.frame_bytes + L.off;
-        const int cq = tid & 15, rs = tid >> 4;
-        unsigned col[8][4];
+        const int og = tid & 15, lr = tid >> 4;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const unsigned lo = s_row[(2 * rs + r) * 32 + 2 * cq], hi = s_row[(2 * rs + r) * 32 + 2 * cq + 1];
-            col[r][0] = lo & 0xffffu; col[r][1] = lo >> 16; col[r][2] = hi & 0xffffu; col[r][3] = hi >> 16;
-        }
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int gy = y0 + 2 * rs + rr;
-            if (gy >= h) break;
-            uint32_t packed = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const unsigned acc = 18u * (col[rr][j] + col[rr + 6][j]) + 34u * (col[rr + 1][j] + col[rr + 5][j]) +
-                                     49u * (col[rr + 2][j] + col[rr + 4][j]) + 55u * col[rr + 3][j] + 32768u;
-                packed |= min(acc >> 16, 255u) << (8 * j);
-            }
-            *reinterpret_cast<uint32_t*>(blur + (size_t)gy * L.pitch + x0 + 4 * cq) = packed;
+        for (int half = 0; half < 2; half++) {
+            const int ly = lr + 16 * half;
+            const int gy = y0 + ly;
+            const uint2* vrow = reinterpret_cast<const uint2*>(s_v + ly * kVPitch) + og;   // group og + 1 is the item's own
+            const uint2 A = vrow[0], B = vrow[1], C = vrow[2];
+            const unsigned rnd = 0xff008000u;
+            // weights as {low half, high half}
+            const unsigned o0 = dot2(A.y, 18u | 49u << 16, dot2(A.x, 34u << 16, dot2(B.x, 55u | 34u << 16, dot2(B.y, 49u | 18u << 16, rnd))));
+            const unsigned o1 = dot2(A.x, 18u << 16, dot2(A.y, 34u << 16, dot2(B.x, 49u | 49u << 16,
+                                dot2(B.y, 55u | 34u << 16, dot2(C.x, 18u, rnd)))));
+            const unsigned o2 = dot2(A.y, 18u << 16, dot2(B.x, 34u | 55u << 16, dot2(B.y, 49u | 49u << 16,
+                                dot2(C.x, 34u, dot2(C.y, 18u, rnd)))));
+            const unsigned o3 = dot2(B.x, 18u | 49u << 16, dot2(B.y, 34u | 55u << 16, dot2(C.x, 49u | 18u << 16, dot2(C.y, 34u, rnd))));
+            // byte 2 of o0 .. o3 -> bytes 0 .. 3
+            const unsigned lo = __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u), hi = __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);
+            if (gy < h) *reinterpret_cast<uint32_t*>(blur + (size_t)gy * L.pitch + x0 + 4 * og) = lo | hi;
         }
     }
-    // (the barrier after the blur row pass also completed the survivor list)
+    lds_barrier();   // the survivor list and the histogram are complete
     {
         const unsigned ns = min(s_n[2], (unsigned)kTileListCap);
         const size_t gt = (size_t)b * a.g.total_tiles + ftile;
