@@ -122,9 +122,11 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_n[3];   // lengths of list 1, list 2 and the survivor list
     __shared__ unsigned s_cellbest[(kFastTileW / 8) * (kFastTileH / 8)];   // grid cells of >= 8 x 8 pixels
-    __shared__ uint32_t s_surv[kTileListCap];   // this tile's survivors: lx | ly << 6 | score << 16
     uint16_t* s_list1 = reinterpret_cast<uint16_t*>(s_scratch);
     unsigned* s_v = reinterpret_cast<unsigned*>(s_scratch);   // [32][18] {even, odd} 16-bit column sums
+    // this tile's survivors, lx | ly << 6 | score << 16, over the split tile (dead once the vertical blur pass is done)
+    uint32_t* s_surv = reinterpret_cast<uint32_t*>(s_eo);
+    static_assert(kTileListCap * 4 <= (int)sizeof(s_eo), "survivor list must fit the split tile");
     static_assert(kScPitch == kImgPitch, "score tile and image tile share one pitch");
     static_assert(kListBytes <= (int)sizeof(s_scratch), "list 1 must fit the scratch region");
     constexpr int P = kImgPitch;
@@ -171,24 +173,34 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     // ---- stage image tile + halo, reflect-101 outside the image ----
     if (in_grid) {
         const int gx = x0 - kImgHalo + 4 * cg;
-        const bool fast = aligned && gx >= 0 && gx + 3 < w;
-        const bool near = w >= 4 && h >= 4;
-        int rx[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) rx[j] = near ? reflect101_near(gx + j, w) : reflect101(gx + j, w);
         uint32_t v[3];
+        // workgroup-uniform cases: a tile whose halo lies inside the level needs no reflection at all
+        const bool inside = aligned && x0 >= kImgHalo && x0 + kFastTileW + kImgHalo <= w && y0 >= kImgHalo &&
+                            y0 + kFastTileH + kImgHalo <= h;
+        if (inside) {
+            const uint8_t* p0 = img + (size_t)(y0 - kImgHalo + rr) * pitch + gx;
 #pragma unroll
-        for (int it = 0; it < 3; it++) {
-            const int r = rr + 14 * it;
-            v[it] = 0;
-            if (r < kImgRows) {
-                const int gy = near ? reflect101_near(y0 - kImgHalo + r, h) : reflect101(y0 - kImgHalo + r, h);
-                const uint8_t* row = img + (size_t)gy * pitch;
-                if (fast) {
-                    v[it] = *reinterpret_cast<const uint32_t*>(row + gx);
-                } else {
-                    v[it] = (uint32_t)row[rx[0]] | ((uint32_t)row[rx[1]] << 8) | ((uint32_t)row[rx[2]] << 16) |
-                            ((uint32_t)row[rx[3]] << 24);
+            for (int it = 0; it < 3; it++)
+                v[it] = rr + 14 * it < kImgRows ? *reinterpret_cast<const uint32_t*>(p0 + (size_t)(14 * it) * pitch) : 0u;
+        } else {
+            const bool fast = aligned && gx >= 0 && gx + 3 < w;
+            const bool near = w >= 4 && h >= 4;
+            int rx[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) rx[j] = near ? reflect101_near(gx + j, w) : reflect101(gx + j, w);
+#pragma unroll
+            for (int it = 0; it < 3; it++) {
+                const int r = rr + 14 * it;
+                v[it] = 0;
+                if (r < kImgRows) {
+                    const int gy = near ? reflect101_near(y0 - kImgHalo + r, h) : reflect101(y0 - kImgHalo + r, h);
+                    const uint8_t* row = img + (size_t)gy * pitch;
+                    if (fast) {
+                        v[it] = *reinterpret_cast<const uint32_t*>(row + gx);
+                    } else {
+                        v[it] = (uint32_t)row[rx[0]] | ((uint32_t)row[rx[1]] << 8) | ((uint32_t)row[rx[2]] << 16) |
+                                ((uint32_t)row[rx[3]] << 24);
+                    }
                 }
             }
         }
@@ -228,7 +240,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
                     cmask |= 5u << ((j & 1) + 16 * (j >> 1));
             }
         }
-        const unsigned KB = 0x02000200u - (unsigned)(t + 1) * 0x00010001u;
+        // held in a vector register: an add with a scalar-register operand issues at half rate
+        unsigned KB = 0x02000200u - (unsigned)(t + 1) * 0x00010001u;
+        asm volatile("v_mov_b32 %0, %0" : "+v"(KB));
         unsigned Y = 0;   // flags of the thread's three items: item `it` shifted left by 4 it
 #pragma unroll
         for (int it = 0; it < 3; it++) {

@@ -13,4 +13,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq2 -- $BENCH > $OUT/pmc_sq2_bench.json 2> $OUT/pmc_sq2.err || exit 1
 echo done
