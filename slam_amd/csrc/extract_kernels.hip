@@ -664,8 +664,12 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs 
 }
 
 // ---------------------------------------------------------------------------
-// Describe: one single-wave workgroup per keypoint, so everything derived from the
-// keypoint index is scalar.  Two patches are staged in LDS with aligned 4-byte loads:
+// Describe: a workgroup of 4 waves takes 64 consecutive keypoints of one frame.  A wave
+// handles one keypoint at a time (everything derived from the keypoint index is scalar),
+// 16 in a row: first the intensity centroids, then -- one keypoint per lane, so that the
+// per-keypoint scalar arithmetic (atan2, the double-precision cos / sin) is done once per
+// keypoint instead of once per lane -- the angles, then the descriptors.
+// Two patches are staged in LDS with aligned 4-byte loads:
 // 31 x 31 of the unblurred level (intensity centroid over the radius-15 disc) and
 // 37 x 37 of the blurred level (256 rotated rBRIEF comparisons, 4 per lane, assembled
 // by ballot; the rotated pattern reaches at most 18 pixels).  Keypoints lie >= 31
@@ -735,102 +739,148 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
-__global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
-    __shared__ __align__(16) uint8_t s_all[kWaveLds + 64];
+constexpr int kDescKps = 64;                   // keypoints per workgroup
+constexpr int kDescPerWave = kDescKps / 4;     // handled one after the other by each of the 4 waves
+
+__global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
+    __shared__ __align__(16) uint8_t s_all[4][kWaveLds + 64];
+    __shared__ int s_m[kDescKps][2];       // m10, m01 of every keypoint of the workgroup
+    __shared__ float s_rot[kDescKps][2];   // cos, sin of its angle
     // 1-D grid, frame index fastest, so the workgroups beyond the last keypoint of
     // every frame (they exit at once) sit at the end of the grid.
     const int b = blockIdx.x % a.batch;
-    const int i = blockIdx.x / a.batch;
+    const int i0 = (blockIdx.x / a.batch) * kDescKps;
     const int n = min(a.sel[b].total, a.capacity);
-    if (i >= n) return;
-    const int lane = threadIdx.x;
-    uint8_t* s_u = s_all;
-    uint8_t* s_b = s_all + kURows * kUPitch;
-    // the lane's four pattern rows (pair p = 64*k + lane), fetched ahead of everything else
-    float4 pat[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const float4*>(c_pattern)[64 * k + lane];
+    if (i0 >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: everything derived from it too
+    uint8_t* s_u = s_all[wave];
+    uint8_t* s_b = s_all[wave] + kURows * kUPitch;
+    const uint8_t* pyr = a.pyr + (size_t)b * a.g.frame_bytes;
+    const uint8_t* blurf = a.blur + (size_t)b * a.g.frame_bytes;
+    const uint32_t* kpxy = a.kpxy + (size_t)b * a.capacity;
 
-    slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity + i;
-    const uint32_t xy = a.kpxy[(size_t)b * a.capacity + i];
-    const int x = (int)(xy & 0x3fffu), y = (int)((xy >> 14) & 0x3fffu);
-    const int l = (int)(xy >> 28);
-    const LevelGeom& L = a.g.lv[l];
-    // Both patches must lie inside the level.  The selection kernel only emits positions at least
-    // `edge` (>= 31) pixels from the border, so this rejects nothing it wrote; it keeps a record that
-    // was never written (zeros) or a count that ran ahead of the records from becoming a wild read.
-    // (24 = patch radius 18 + the up to 3 + 3 bytes the aligned dword loads reach further.)
-    if (l >= a.g.nlevels || x < 24 || y < 24 || x >= L.w - 24 || y >= L.h - 24) return;
-    const uint8_t* img;
-    int pitch;
-    bool aligned = true;
-    if (l == 0) {
-        img = a.img0 + (size_t)b * a.img0_frame_pitch;
-        pitch = a.img0_pitch;
-        aligned = a.img0_aligned != 0;
-    } else {
-        img = a.pyr + (size_t)b * a.g.frame_bytes + L.off;
-        pitch = L.pitch;
-    }
-    const uint8_t* blur = a.blur + (size_t)b * a.g.frame_bytes + L.off;
-    const int su = stage_patch<kURad, kUPitch>(img, pitch, aligned, x, y, s_u, lane);
-    const int sb = stage_patch<kBRad, kBPitch>(blur, L.pitch, true, x, y, s_b, lane);
-    // LDS traffic of one wave executes in order; this only keeps the compiler from
-    // moving the reads above the writes.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // Position of keypoint i; false if its patches would leave the level.  The selection kernel only
+    // emits positions at least `edge` (>= 31) pixels from the border, so this rejects nothing it wrote;
+    // it keeps a record that was never written (zeros) or a count that ran ahead of the records from
+    // becoming a wild read.  (24 = patch radius 18 + the up to 3 + 3 bytes the aligned dword loads
+    // reach further.)
+    auto locate = [&](int i, int& x, int& y, int& l) -> bool {
+        const uint32_t xy = kpxy[i];
+        x = (int)(xy & 0x3fffu);
+        y = (int)((xy >> 14) & 0x3fffu);
+        l = (int)(xy >> 28);
+        if (l >= a.g.nlevels) return false;
+        const LevelGeom& L = a.g.lv[l];
+        return !(x < 24 || y < 24 || x >= L.w - 24 || y >= L.h - 24);
+    };
 
-    // ---- intensity centroid ----
+    // ---- pass 1: intensity centroid of every keypoint (one wave per keypoint, 16 in a row) ----
     // Lanes 0-30 own the columns u = -15..15 for the rows v = -15..0, lanes 32-62 the
     // same columns for v = 1..15.  A lane adds up its column (rows outside the disc
     // masked off) and the row-weighted sum; the column weight is applied once.
-    int m10, m01;
-    {
-        const int col = lane & 31, half = lane >> 5;
-        const int u = col - 15;
-        const int vlim = col < 31 ? disc_half_width(u < 0 ? -u : u) : -1;  // |v| <= vlim is inside
-        const int vbase = half ? 1 : -15;                                  // v = vbase + vv, vv = 0..15
-        const int lo = half ? 0 : 15 - vlim, hi = half ? vlim - 1 : 15;    // vv range inside the disc
-        const unsigned rows = hi >= lo ? (2u << hi) - (1u << lo) : 0u;
-        // column 31 (u = 16) and row v = 16 are masked off; their reads stay inside s_all
-        const uint8_t* colp = s_u + (kURad + vbase) * kUPitch + su + kURad + u;
-        int colsum = 0, vsum = 0;
+    const int col = lane & 31, half = lane >> 5;
+    const int u = col - 15;
+    const int vlim = col < 31 ? disc_half_width(u < 0 ? -u : u) : -1;  // |v| <= vlim is inside
+    const int vbase = half ? 1 : -15;                                  // v = vbase + vv, vv = 0..15
+    const int lo = half ? 0 : 15 - vlim, hi = half ? vlim - 1 : 15;    // vv range inside the disc
+    const unsigned rows = hi >= lo ? (2u << hi) - (1u << lo) : 0u;
+#pragma unroll 1
+    for (int j = 0; j < kDescPerWave; j++) {
+        const int slot = wave * kDescPerWave + j, i = i0 + slot;
+        if (i >= n) break;
+        int x, y, l;
+        int m10 = 0, m01 = 0;
+        if (locate(i, x, y, l)) {
+            const uint8_t* img;
+            int pitch;
+            bool aligned = true;
+            if (l == 0) {
+                img = a.img0 + (size_t)b * a.img0_frame_pitch;
+                pitch = a.img0_pitch;
+                aligned = a.img0_aligned != 0;
+            } else {
+                img = pyr + a.g.lv[l].off;
+                pitch = a.g.lv[l].pitch;
+            }
+            const int su = stage_patch<kURad, kUPitch>(img, pitch, aligned, x, y, s_u, lane);
+            // LDS traffic of one wave executes in order; this only keeps the compiler from
+            // moving the reads above the writes.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // column 31 (u = 16) and row v = 16 are masked off; their reads stay inside s_all
+            const uint8_t* colp = s_u + (kURad + vbase) * kUPitch + su + kURad + u;
+            int colsum = 0, vsum = 0;
 #pragma unroll
-        for (int vv = 0; vv < 16; vv++) {
-            int val = colp[vv * kUPitch];
-            val &= ((int)(rows << (31 - vv))) >> 31;
-            colsum += val;
-            vsum += vv * val;
+            for (int vv = 0; vv < 16; vv++) {
+                int val = colp[vv * kUPitch];
+                val &= ((int)(rows << (31 - vv))) >> 31;
+                colsum += val;
+                vsum += vv * val;
+            }
+            m10 = wave_sum_i32(u * colsum);
+            m01 = wave_sum_i32(vbase * colsum + vsum);
+            // the next keypoint's patch overwrites s_u: reads first
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        m10 = wave_sum_i32(u * colsum);
-        m01 = wave_sum_i32(vbase * colsum + vsum);
+        if (lane == 0) { s_m[slot][0] = m10; s_m[slot][1] = m01; }
     }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-    // ---- rBRIEF: pair p = 64*k + lane, k = 0..3; ballot k holds bytes 8k..8k+7 ----
-    const float rad = SA_FMUL(angle, (float)(3.14159265358979323846 / 180.0));
-    float ca, sb_;
-    sincos_f32(rad, &ca, &sb_);
-    const uint8_t* bc = s_b + kBRad * kBPitch + sb + kBRad;
-    unsigned long long bits[4];
+    __syncthreads();
+    // ---- pass 2: angle, cos and sin of all keypoints of the workgroup at once, one per lane ----
+    int px, py, pl;
+    if (threadIdx.x < kDescKps && i0 + (int)threadIdx.x < n && locate(i0 + (int)threadIdx.x, px, py, pl)) {
+        const int slot = threadIdx.x;
+        const float angle = fast_atan2_deg((float)s_m[slot][1], (float)s_m[slot][0]);
+        const float rad = SA_FMUL(angle, (float)(3.14159265358979323846 / 180.0));
+        float ca, sn;
+        sincos_f32(rad, &ca, &sn);
+        s_rot[slot][0] = ca;
+        s_rot[slot][1] = sn;
+        a.kp[(size_t)b * a.capacity + i0 + slot].angle = angle;
+    }
+    __syncthreads();
+    // ---- pass 3: rBRIEF, pair p = 64*k + lane, k = 0..3; ballot k holds bytes 8k..8k+7 ----
+    float4 pat[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int ix0 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].x, ca), SA_FMUL(pat[k].y, sb_)));
-        const int iy0 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].x, sb_), SA_FMUL(pat[k].y, ca)));
-        const int ix1 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].z, ca), SA_FMUL(pat[k].w, sb_)));
-        const int iy1 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].z, sb_), SA_FMUL(pat[k].w, ca)));
-        const int t0 = bc[iy0 * kBPitch + ix0];
-        const int t1 = bc[iy1 * kBPitch + ix1];
-        bits[k] = __ballot(t0 < t1);
-    }
-    if (lane == 0) {
-        uint4* out = reinterpret_cast<uint4*>(a.desc + ((size_t)b * a.capacity + i) * 32);
-        out[0] = make_uint4((unsigned)bits[0], (unsigned)(bits[0] >> 32), (unsigned)bits[1], (unsigned)(bits[1] >> 32));
-        out[1] = make_uint4((unsigned)bits[2], (unsigned)(bits[2] >> 32), (unsigned)bits[3], (unsigned)(bits[3] >> 32));
-        kp->angle = angle;
-        kp->x = SA_FMUL((float)x, L.scale);
-        kp->y = SA_FMUL((float)y, L.scale);
+    for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const float4*>(c_pattern)[64 * k + lane];
+#pragma unroll 1
+    for (int j = 0; j < kDescPerWave; j++) {
+        const int slot = wave * kDescPerWave + j, i = i0 + slot;
+        if (i >= n) break;
+        int x, y, l;
+        if (!locate(i, x, y, l)) continue;
+        const LevelGeom& L = a.g.lv[l];
+        const int sb = stage_patch<kBRad, kBPitch>(blurf + L.off, L.pitch, true, x, y, s_b, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float ca = s_rot[slot][0], sb_ = s_rot[slot][1];
+        const uint8_t* bc = s_b + kBRad * kBPitch + sb + kBRad;
+        unsigned long long bits[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int ix0 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].x, ca), SA_FMUL(pat[k].y, sb_)));
+            const int iy0 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].x, sb_), SA_FMUL(pat[k].y, ca)));
+            const int ix1 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].z, ca), SA_FMUL(pat[k].w, sb_)));
+            const int iy1 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].z, sb_), SA_FMUL(pat[k].w, ca)));
+            const int t0 = bc[iy0 * kBPitch + ix0];
+            const int t1 = bc[iy1 * kBPitch + ix1];
+            bits[k] = __ballot(t0 < t1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) {
+            uint4* out = reinterpret_cast<uint4*>(a.desc + ((size_t)b * a.capacity + i) * 32);
+            out[0] = make_uint4((unsigned)bits[0], (unsigned)(bits[0] >> 32), (unsigned)bits[1], (unsigned)(bits[1] >> 32));
+            out[1] = make_uint4((unsigned)bits[2], (unsigned)(bits[2] >> 32), (unsigned)bits[3], (unsigned)(bits[3] >> 32));
+            slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity + i;
+            kp->x = SA_FMUL((float)x, L.scale);
+            kp->y = SA_FMUL((float)y, L.scale);
+        }
     }
 }
 
@@ -856,10 +906,10 @@ int launch_select_compact(const SelectCompactArgs& a, int batch, hipStream_t st)
 int launch_describe(const DescribeArgs& a, int batch, hipStream_t st) {
     DescribeArgs d = a;
     d.batch = batch;
-    const long long blocks = (long long)a.capacity * batch;
+    const long long blocks = (long long)div_up(a.capacity, kDescKps) * batch;
     if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "describe: capacity x batch too large for one launch");
     dim3 grid((unsigned)blocks);
-    hipLaunchKernelGGL(describe_kernel, grid, dim3(64), 0, st, d);
+    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), 0, st, d);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }
