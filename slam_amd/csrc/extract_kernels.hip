@@ -728,6 +728,44 @@ __device__ __forceinline__ int stage_patch(const uint8_t* img, int pitch, bool a
     return 0;
 }
 
+// The same copy in two steps, so that the loads of the next keypoint's patch are in flight while the
+// current one is processed: patch_load issues the aligned dword loads into registers (the image rows
+// must be 4-byte aligned), patch_store writes them to LDS and returns the column shift.
+template <int R, int PITCH>
+struct PatchRegs {
+    static constexpr int ROWS = 2 * R + 1, DW = PITCH / 4, RPI = 64 / DW, ITERS = (ROWS + RPI - 1) / RPI;
+    uint32_t v[ITERS];
+    int shift;
+};
+
+template <int R, int PITCH>
+__device__ __forceinline__ void patch_load(PatchRegs<R, PITCH>& pr, const uint8_t* img, int pitch, int x, int y, int lane) {
+    typedef PatchRegs<R, PITCH> PR;
+    const uint8_t* p0 = img + (size_t)(y - R) * pitch + (x - R);
+    pr.shift = (int)(reinterpret_cast<uintptr_t>(p0) & 3);
+    const uint8_t* base = p0 - pr.shift;
+    const int lr = lane / PR::DW, lc = lane - lr * PR::DW;
+    const unsigned voff = (unsigned)(lr * pitch + 4 * lc);
+#pragma unroll
+    for (int it = 0; it < PR::ITERS; it++) {
+        pr.v[it] = 0;
+        if (lr < PR::RPI && lr + it * PR::RPI < PR::ROWS)
+            pr.v[it] = *reinterpret_cast<const uint32_t*>(base + (size_t)(it * PR::RPI) * pitch + voff);
+    }
+}
+
+template <int R, int PITCH>
+__device__ __forceinline__ int patch_store(const PatchRegs<R, PITCH>& pr, uint8_t* dst, int lane) {
+    typedef PatchRegs<R, PITCH> PR;
+    const int lr = lane / PR::DW, lc = lane - lr * PR::DW;
+    uint8_t* d = dst + lr * PITCH + 4 * lc;
+#pragma unroll
+    for (int it = 0; it < PR::ITERS; it++)
+        if (lr < PR::RPI && lr + it * PR::RPI < PR::ROWS)
+            *reinterpret_cast<uint32_t*>(d + it * PR::RPI * PITCH) = pr.v[it];
+    return pr.shift;
+}
+
 // Sum over the 64 lanes, returned in a scalar register: butterfly inside each row of
 // 16 lanes with DPP, then the four row sums are read out.
 __device__ __forceinline__ int wave_sum_i32(int v) {
@@ -785,16 +823,10 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
     const int vbase = half ? 1 : -15;                                  // v = vbase + vv, vv = 0..15
     const int lo = half ? 0 : 15 - vlim, hi = half ? vlim - 1 : 15;    // vv range inside the disc
     const unsigned rows = hi >= lo ? (2u << hi) - (1u << lo) : 0u;
-#pragma unroll 1
-    for (int j = 0; j < kDescPerWave; j++) {
-        const int slot = wave * kDescPerWave + j, i = i0 + slot;
-        if (i >= n) break;
-        int x, y, l;
-        int m10 = 0, m01 = 0;
-        if (locate(i, x, y, l)) {
-            const uint8_t* img;
-            int pitch;
-            bool aligned = true;
+    {
+        // level image of keypoint level l
+        auto level_image = [&](int l, const uint8_t*& img, int& pitch, bool& aligned) {
+            aligned = true;
             if (l == 0) {
                 img = a.img0 + (size_t)b * a.img0_frame_pitch;
                 pitch = a.img0_pitch;
@@ -803,30 +835,66 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
                 img = pyr + a.g.lv[l].off;
                 pitch = a.g.lv[l].pitch;
             }
-            const int su = stage_patch<kURad, kUPitch>(img, pitch, aligned, x, y, s_u, lane);
-            // LDS traffic of one wave executes in order; this only keeps the compiler from
-            // moving the reads above the writes.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // column 31 (u = 16) and row v = 16 are masked off; their reads stay inside s_all
-            const uint8_t* colp = s_u + (kURad + vbase) * kUPitch + su + kURad + u;
-            int colsum = 0, vsum = 0;
-#pragma unroll
-            for (int vv = 0; vv < 16; vv++) {
-                int val = colp[vv * kUPitch];
-                val &= ((int)(rows << (31 - vv))) >> 31;
-                colsum += val;
-                vsum += vv * val;
-            }
-            m10 = wave_sum_i32(u * colsum);
-            m01 = wave_sum_i32(vbase * colsum + vsum);
-            // the next keypoint's patch overwrites s_u: reads first
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        PatchRegs<kURad, kUPitch> cur;
+        int x = 0, y = 0, l = 0;
+        bool ok = false, al = true;
+        const int first = i0 + wave * kDescPerWave;
+        if (first < n && (ok = locate(first, x, y, l))) {
+            const uint8_t* img; int pitch;
+            level_image(l, img, pitch, al);
+            if (al) patch_load(cur, img, pitch, x, y, lane);
         }
-        if (lane == 0) { s_m[slot][0] = m10; s_m[slot][1] = m01; }
+#pragma unroll 1
+        for (int j = 0; j < kDescPerWave; j++) {
+            const int slot = wave * kDescPerWave + j, i = i0 + slot;
+            if (i >= n) break;
+            int su = 0;
+            if (ok) {
+                if (al) {
+                    su = patch_store(cur, s_u, lane);
+                } else {
+                    const uint8_t* img; int pitch; bool dummy;
+                    level_image(l, img, pitch, dummy);
+                    su = stage_patch<kURad, kUPitch>(img, pitch, false, x, y, s_u, lane);
+                }
+            }
+            // the next keypoint's loads go out before this one's arithmetic
+            PatchRegs<kURad, kUPitch> nxt;
+            int xn = 0, yn = 0, ln = 0;
+            bool okn = false, aln = true;
+            if (j + 1 < kDescPerWave && i + 1 < n && (okn = locate(i + 1, xn, yn, ln))) {
+                const uint8_t* img; int pitch;
+                level_image(ln, img, pitch, aln);
+                if (aln) patch_load(nxt, img, pitch, xn, yn, lane);
+            }
+            int m10 = 0, m01 = 0;
+            if (ok) {
+                // LDS traffic of one wave executes in order; this only keeps the compiler from
+                // moving the reads above the writes.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // column 31 (u = 16) and row v = 16 are masked off; their reads stay inside s_all
+                const uint8_t* colp = s_u + (kURad + vbase) * kUPitch + su + kURad + u;
+                int colsum = 0, vsum = 0;
+#pragma unroll
+                for (int vv = 0; vv < 16; vv++) {
+                    int val = colp[vv * kUPitch];
+                    val &= ((int)(rows << (31 - vv))) >> 31;
+                    colsum += val;
+                    vsum += vv * val;
+                }
+                m10 = wave_sum_i32(u * colsum);
+                m01 = wave_sum_i32(vbase * colsum + vsum);
+                // the next keypoint's patch overwrites s_u: reads first
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            if (lane == 0) { s_m[slot][0] = m10; s_m[slot][1] = m01; }
+            cur = nxt; x = xn; y = yn; l = ln; ok = okn; al = aln;
+        }
     }
     __syncthreads();
     // ---- pass 2: angle, cos and sin of all keypoints of the workgroup at once, one per lane ----
@@ -846,40 +914,55 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
     float4 pat[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const float4*>(c_pattern)[64 * k + lane];
+    {
+        PatchRegs<kBRad, kBPitch> cur;
+        int x = 0, y = 0, l = 0;
+        bool ok = false;
+        const int first = i0 + wave * kDescPerWave;
+        if (first < n && (ok = locate(first, x, y, l)))
+            patch_load(cur, blurf + a.g.lv[l].off, a.g.lv[l].pitch, x, y, lane);
 #pragma unroll 1
-    for (int j = 0; j < kDescPerWave; j++) {
-        const int slot = wave * kDescPerWave + j, i = i0 + slot;
-        if (i >= n) break;
-        int x, y, l;
-        if (!locate(i, x, y, l)) continue;
-        const LevelGeom& L = a.g.lv[l];
-        const int sb = stage_patch<kBRad, kBPitch>(blurf + L.off, L.pitch, true, x, y, s_b, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float ca = s_rot[slot][0], sb_ = s_rot[slot][1];
-        const uint8_t* bc = s_b + kBRad * kBPitch + sb + kBRad;
-        unsigned long long bits[4];
+        for (int j = 0; j < kDescPerWave; j++) {
+            const int slot = wave * kDescPerWave + j, i = i0 + slot;
+            if (i >= n) break;
+            int sb = 0;
+            if (ok) sb = patch_store(cur, s_b, lane);
+            PatchRegs<kBRad, kBPitch> nxt;
+            int xn = 0, yn = 0, ln = 0;
+            bool okn = false;
+            if (j + 1 < kDescPerWave && i + 1 < n && (okn = locate(i + 1, xn, yn, ln)))
+                patch_load(nxt, blurf + a.g.lv[ln].off, a.g.lv[ln].pitch, xn, yn, lane);
+            if (ok) {
+                const LevelGeom& L = a.g.lv[l];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const float ca = s_rot[slot][0], sb_ = s_rot[slot][1];
+                const uint8_t* bc = s_b + kBRad * kBPitch + sb + kBRad;
+                unsigned long long bits[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int ix0 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].x, ca), SA_FMUL(pat[k].y, sb_)));
-            const int iy0 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].x, sb_), SA_FMUL(pat[k].y, ca)));
-            const int ix1 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].z, ca), SA_FMUL(pat[k].w, sb_)));
-            const int iy1 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].z, sb_), SA_FMUL(pat[k].w, ca)));
-            const int t0 = bc[iy0 * kBPitch + ix0];
-            const int t1 = bc[iy1 * kBPitch + ix1];
-            bits[k] = __ballot(t0 < t1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane == 0) {
-            uint4* out = reinterpret_cast<uint4*>(a.desc + ((size_t)b * a.capacity + i) * 32);
-            out[0] = make_uint4((unsigned)bits[0], (unsigned)(bits[0] >> 32), (unsigned)bits[1], (unsigned)(bits[1] >> 32));
-            out[1] = make_uint4((unsigned)bits[2], (unsigned)(bits[2] >> 32), (unsigned)bits[3], (unsigned)(bits[3] >> 32));
-            slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity + i;
-            kp->x = SA_FMUL((float)x, L.scale);
-            kp->y = SA_FMUL((float)y, L.scale);
+                for (int k = 0; k < 4; k++) {
+                    const int ix0 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].x, ca), SA_FMUL(pat[k].y, sb_)));
+                    const int iy0 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].x, sb_), SA_FMUL(pat[k].y, ca)));
+                    const int ix1 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].z, ca), SA_FMUL(pat[k].w, sb_)));
+                    const int iy1 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].z, sb_), SA_FMUL(pat[k].w, ca)));
+                    const int t0 = bc[iy0 * kBPitch + ix0];
+                    const int t1 = bc[iy1 * kBPitch + ix1];
+                    bits[k] = __ballot(t0 < t1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane == 0) {
+                    uint4* out = reinterpret_cast<uint4*>(a.desc + ((size_t)b * a.capacity + i) * 32);
+                    out[0] = make_uint4((unsigned)bits[0], (unsigned)(bits[0] >> 32), (unsigned)bits[1], (unsigned)(bits[1] >> 32));
+                    out[1] = make_uint4((unsigned)bits[2], (unsigned)(bits[2] >> 32), (unsigned)bits[3], (unsigned)(bits[3] >> 32));
+                    slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity + i;
+                    kp->x = SA_FMUL((float)x, L.scale);
+                    kp->y = SA_FMUL((float)y, L.scale);
+                }
+            }
+            cur = nxt; x = xn; y = yn; l = ln; ok = okn;
         }
     }
 }
