@@ -286,7 +286,10 @@ static int make_pyramid_plan(const PyrGeom& g, HostPyramidPlan& plan) {
         if (!fill(sw, dw, xo[l], xt[l]) || !fill(sh, dh, yo[l], yt[l])) SA_FAIL(SLAM_AMD_ERR_ARG, "image too large");
     }
     // groups of consecutive levels whose regions fit the LDS budget, tiles of 32 (else 16, 8) pixels
-    constexpr size_t kLdsBudget = 48 * 1024;
+#ifndef SA_PYR_LDS_KB
+#define SA_PYR_LDS_KB 48
+#endif
+    constexpr size_t kLdsBudget = SA_PYR_LDS_KB * 1024;
     auto try_group = [&](int first, int last, int T, HostGroup& out) {
         out.first = first; out.last = last; out.T = T;
         out.ntx = div_up(ws[last], T); out.nty = div_up(hs[last], T);
@@ -301,7 +304,10 @@ static int make_pyramid_plan(const PyrGeom& g, HostPyramidPlan& plan) {
     for (int first = 1; first < g.nlevels;) {
         HostGroup best;
         bool found = false;
-        for (int T : {32, 16, 8}) {
+#ifndef SA_PYR_TILES
+#define SA_PYR_TILES {32, 16, 8}
+#endif
+        for (int T : SA_PYR_TILES) {
             // the longest run of levels from `first` that fits with this tile size; larger tiles
             // are preferred (fewer, larger workgroups: less recomputation at the tile borders)
             int last = first;

@@ -664,11 +664,11 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs 
 }
 
 // ---------------------------------------------------------------------------
-// Describe: a workgroup of 4 waves takes 64 consecutive keypoints of one frame.  A wave
-// handles one keypoint at a time (everything derived from the keypoint index is scalar),
-// 16 in a row: first the intensity centroids, then -- one keypoint per lane, so that the
-// per-keypoint scalar arithmetic (atan2, the double-precision cos / sin) is done once per
-// keypoint instead of once per lane -- the angles, then the descriptors.
+// Describe: a single-wave workgroup takes 8 consecutive keypoints of one frame, one at a
+// time (everything derived from the keypoint index is scalar): first the intensity
+// centroids of all 8, then -- one keypoint per lane, so that the per-keypoint scalar
+// arithmetic (atan2, the double-precision cos / sin) is done once for the 8 instead of 8
+// times on all lanes -- the angles, then the descriptors.  No workgroup barrier is needed.
 // Two patches are staged in LDS with aligned 4-byte loads:
 // 31 x 31 of the unblurred level (intensity centroid over the radius-15 disc) and
 // 37 x 37 of the blurred level (256 rotated rBRIEF comparisons, 4 per lane, assembled
@@ -777,11 +777,14 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
-constexpr int kDescKps = 64;                   // keypoints per workgroup
-constexpr int kDescPerWave = kDescKps / 4;     // handled one after the other by each of the 4 waves
+#ifndef SA_DESC_KPS
+#define SA_DESC_KPS 8
+#endif
+constexpr int kDescKps = SA_DESC_KPS;                   // keypoints per (single-wave) workgroup
+constexpr int kDescPerWave = kDescKps;         // handled one after the other
 
-__global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
-    __shared__ __align__(16) uint8_t s_all[4][kWaveLds + 64];
+__global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
+    __shared__ __align__(16) uint8_t s_all[1][kWaveLds + 64];
     __shared__ int s_m[kDescKps][2];       // m10, m01 of every keypoint of the workgroup
     __shared__ float s_rot[kDescKps][2];   // cos, sin of its angle
     // 1-D grid, frame index fastest, so the workgroups beyond the last keypoint of
@@ -790,8 +793,8 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
     const int i0 = (blockIdx.x / a.batch) * kDescKps;
     const int n = min(a.sel[b].total, a.capacity);
     if (i0 >= n) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: everything derived from it too
+    const int lane = threadIdx.x;
+    constexpr int wave = 0;
     uint8_t* s_u = s_all[wave];
     uint8_t* s_b = s_all[wave] + kURows * kUPitch;
     const uint8_t* pyr = a.pyr + (size_t)b * a.g.frame_bytes;
@@ -896,7 +899,9 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
             cur = nxt; x = xn; y = yn; l = ln; ok = okn; al = aln;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- pass 2: angle, cos and sin of all keypoints of the workgroup at once, one per lane ----
     int px, py, pl;
     if (threadIdx.x < kDescKps && i0 + (int)threadIdx.x < n && locate(i0 + (int)threadIdx.x, px, py, pl)) {
@@ -909,7 +914,9 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs a) {
         s_rot[slot][1] = sn;
         a.kp[(size_t)b * a.capacity + i0 + slot].angle = angle;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- pass 3: rBRIEF, pair p = 64*k + lane, k = 0..3; ballot k holds bytes 8k..8k+7 ----
     float4 pat[4];
 #pragma unroll
@@ -992,7 +999,7 @@ int launch_describe(const DescribeArgs& a, int batch, hipStream_t st) {
     const long long blocks = (long long)div_up(a.capacity, kDescKps) * batch;
     if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "describe: capacity x batch too large for one launch");
     dim3 grid((unsigned)blocks);
-    hipLaunchKernelGGL(describe_kernel, grid, dim3(256), 0, st, d);
+    hipLaunchKernelGGL(describe_kernel, grid, dim3(64), 0, st, d);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }
