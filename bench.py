@@ -42,6 +42,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 CLOCK_GHZ = 2.4
 N_SIMD = 1024                  # 256 CUs x 4 SIMD-32; a wave64 VALU instruction holds one for 2 cycles
 VALU_NOMINAL_GCMP = 4914.0     # 256 CU x 128 lanes/clk x 2.4 GHz / 16 ops, for reference only
+# matrix-core ceiling of the ungated matcher: a 32 x 32 block of (train, query) pairs costs 9
+# v_mfma_i32_32x32x32_i8 of 32 cycles each on one of the 1024 SIMDs
+MFMA_I8_PEAK_GCMP = N_SIMD * 2.4e9 * 1024 / (9 * 32) / 1e9
 
 
 def valu_peak_gcmp():
@@ -374,10 +377,18 @@ def run_frames(args):
                         "algorithmic_bytes_per_launch": int(alg_bytes[key])}
             if pmc.get("valu_wave_insts"):
                 # the kernel's other ceiling: VALU issue.  A wave64 VALU instruction holds one of the
-                # 1024 SIMD-32s for 2 cycles, so the launch cannot take less than insts * 2 / 1024 cycles.
-                floor_s = pmc["valu_wave_insts"] * 2.0 / N_SIMD / (CLOCK_GHZ * 1e9)
+                # 1024 SIMDs for 2 cycles if it is one of the few full-rate opcodes and for 4 otherwise
+                # (measured: profiles/*valu_ops_stdout.txt).  nominal = every instruction at 2 cycles;
+                # priced = the measured instruction count at the kernel's static mix of the two classes
+                # (profiles/isa_mix.json, tools/isa_price.py).
+                nominal_s = pmc["valu_wave_insts"] * 2.0 / N_SIMD / (CLOCK_GHZ * 1e9)
                 roofline["valu_issue"] = {"wave_insts_per_launch": int(pmc["valu_wave_insts"]),
-                                          "floor_us": round(floor_s * 1e6, 2), "frac": round(floor_s / avg_s, 4)}
+                                          "floor_us": round(nominal_s * 1e6, 2), "frac": round(nominal_s / avg_s, 4)}
+                cpi = isa_cycles_per_inst(key)
+                if cpi:
+                    priced_s = pmc["valu_wave_insts"] * cpi / N_SIMD / (CLOCK_GHZ * 1e9)
+                    roofline["valu_issue"].update({"cycles_per_inst_priced": cpi, "priced_floor_us": round(priced_s * 1e6, 2),
+                                                   "priced_frac": round(priced_s / avg_s, 4)})
         else:
             # matching is bound by integer VALU throughput (xor + popcount), not HBM or MFMA
             cmp_per_launch = float((counts.astype(np.float64) * np.roll(counts, 1)).sum())
@@ -546,6 +557,16 @@ def pmc_counters(kernel, batch, width, height):
     return out
 
 
+def isa_cycles_per_inst(kernel):
+    """Average issue cycles per VALU instruction of `kernel` at its static mix of full-rate (2-cycle)
+    and other (4-cycle) opcodes, from profiles/isa_mix.json; None if the file has no such kernel."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "isa_mix.json")) as f:
+            return json.load(f)["kernels"][kernel]["cycles_per_inst"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def run_pairs(args, torch, dist, capi, synth, m, dev, ranks, valu_peak):
     """All i<j pairs of n_kf keyframes x n_per descriptors, gates off (the multi-GPU benchmark configuration).
     Sharding, chunking and the gather to rank 0 are the C++ pair shard's (slam_amd_pair_shard_*, RCCL
@@ -577,9 +598,14 @@ def run_pairs(args, torch, dist, capi, synth, m, dev, ranks, valu_peak):
     res = {"workload": "%d keyframes x %d descriptors, all %d pairs i<j, gates off, results gathered to rank 0"
                        % (n_kf, n_per, n_pairs),
            "gcmp_per_s": round(total_cmp / dt / 1e9, 1), "seconds": round(dt, 4), "n_gpus": world,
-           "scaling": "strong", "valu_peak_gcmp_per_gpu": valu_peak,
-           "valu_nominal_gcmp_per_gpu": VALU_NOMINAL_GCMP,
-           "valu_frac": round(total_cmp / dt / 1e9 / (valu_peak * world), 4),
+           "scaling": "strong",
+           # gates off: distances come from v_mfma_i32_32x32x32_i8, nine K-steps of 32 cycles per
+           # 32 x 32 block of pairs on each of the 1024 SIMDs
+           "bound": "mfma", "mfma_peak_gcmp_per_gpu": MFMA_I8_PEAK_GCMP,
+           "mfma_frac": round(total_cmp / dt / 1e9 / (MFMA_I8_PEAK_GCMP * world), 4),
+           "mfma_i8_tops": round(total_cmp / dt * 9 * 32 * 2 / 1e12, 1),
+           # the popcount kernel's measured ceiling (used with a gate on), for comparison
+           "valu_peak_gcmp_per_gpu": valu_peak,
            "host": "C++ pair shard (slam_amd_pair_shard_*), RCCL send/recv in %d chunks" % args.pair_chunks}
     if rank == 0:
         # order-independent checksum of the gathered result, comparable across N
