@@ -362,6 +362,147 @@ int orc_brief_descriptor(const uint8_t* blurred, int stride, int cx, int cy, flo
     return ORC_OK;
 }
 
+/* ---------------------------------------------------------------------------
+ * Option beyond the reference (it has no keypoint distribution step): quadtree
+ * distribution with an exact target count, after ORB-SLAM's DistributeOctTree,
+ * made deterministic.  Input: the NMS survivors of one level inside the border,
+ * cand[3 i] = x, y, score; region [rx0, rx1) x [ry0, ry1); target = the level's quota.
+ *   - n <= target: everything is kept.
+ *   - Roots: nini = max(1, round(W / H)) cells of ceil(W / nini) columns side by side.
+ *   - A cell splits at x0 + ceil(w / 2), y0 + ceil(h / 2); empty children are dropped.
+ *     Cells are kept in path order (root index, then quadrant 2 * lower + right per level).
+ *   - Round: stop when the number of cells reaches the target.  If splitting every cell that
+ *     holds more than one survivor still gives fewer cells than the target, do that and
+ *     start the next round; otherwise split such cells one by one, most populated first
+ *     (path order among equals), until the target is reached, and stop.
+ *   - Every cell keeps its best survivor (highest score, then lowest y, then lowest x); if
+ *     that is more than the target, the best `target` of them by the same order stay.
+ * keep[i] = 1 for the survivors that stay. */
+typedef struct { int x0, x1, y0, y1, begin, count; } qt_cell;
+
+static int qt_better(const int32_t* cand, int a, int b) {   /* a before b in (score desc, y asc, x asc) */
+    if (cand[3 * a + 2] != cand[3 * b + 2]) return cand[3 * a + 2] > cand[3 * b + 2];
+    if (cand[3 * a + 1] != cand[3 * b + 1]) return cand[3 * a + 1] < cand[3 * b + 1];
+    return cand[3 * a] < cand[3 * b];
+}
+
+/* Splits cell c, whose survivors are idx[c.begin .. c.begin + c.count); writes the non-empty
+ * children in quadrant order to out (their index ranges into idx2, filled from *fill on). */
+static int qt_split(const int32_t* cand, const qt_cell* c, const int* idx, int* idx2, int* fill, qt_cell* out) {
+    const int hx = (c->x1 - c->x0 + 1) / 2, hy = (c->y1 - c->y0 + 1) / 2;
+    const int mx = c->x0 + hx, my = c->y0 + hy;
+    int k = 0;
+    for (int q = 0; q < 4; q++) {
+        qt_cell ch;
+        ch.x0 = (q & 1) ? mx : c->x0; ch.x1 = (q & 1) ? c->x1 : mx;
+        ch.y0 = (q & 2) ? my : c->y0; ch.y1 = (q & 2) ? c->y1 : my;
+        ch.begin = *fill; ch.count = 0;
+        for (int j = 0; j < c->count; j++) {
+            const int i = idx[c->begin + j];
+            const int qi = ((cand[3 * i + 1] >= my) << 1) | (cand[3 * i] >= mx);
+            if (qi == q) { idx2[*fill] = i; (*fill)++; ch.count++; }
+        }
+        if (ch.count > 0) out[k++] = ch;
+    }
+    return k;
+}
+
+int orc_quadtree_select(const int32_t* cand, int n, int rx0, int ry0, int rx1, int ry1, int target, uint8_t* keep) {
+    if (n < 0 || target < 0 || (n > 0 && (!cand || !keep)) || rx1 <= rx0 || ry1 <= ry0) return ORC_ERR_ARG;
+    for (int i = 0; i < n; i++) {
+        if (cand[3 * i] < rx0 || cand[3 * i] >= rx1 || cand[3 * i + 1] < ry0 || cand[3 * i + 1] >= ry1) return ORC_ERR_ARG;
+        keep[i] = (uint8_t)(n <= target);
+    }
+    if (n <= target || target == 0) return ORC_OK;
+    const int W = rx1 - rx0, H = ry1 - ry0;
+    int nini = (2 * W + H) / (2 * H);
+    if (nini < 1) nini = 1;
+    const int rw = (W + nini - 1) / nini;
+    /* two generations of cells and of index lists; a generation never holds more than n cells */
+    qt_cell* cells = (qt_cell*)malloc(sizeof(qt_cell) * (size_t)(n + nini) * 2);
+    int* idx = (int*)malloc(sizeof(int) * (size_t)n * 2);
+    int* order = (int*)malloc(sizeof(int) * (size_t)(n + nini));
+    if (!cells || !idx || !order) { free(cells); free(idx); free(order); return ORC_ERR_NOMEM; }
+    qt_cell* cur = cells; qt_cell* nxt = cells + (n + nini);
+    int* icur = idx; int* inxt = idx + n;
+    int ncur = 0, fill = 0;
+    for (int r = 0; r < nini; r++) {
+        qt_cell c;
+        c.x0 = rx0 + r * rw; c.x1 = c.x0 + rw < rx1 ? c.x0 + rw : rx1; c.y0 = ry0; c.y1 = ry1;
+        c.begin = fill; c.count = 0;
+        for (int i = 0; i < n; i++)
+            if (cand[3 * i] >= c.x0 && cand[3 * i] < c.x1) { icur[fill++] = i; c.count++; }
+        if (c.count > 0) cur[ncur++] = c;
+    }
+    for (;;) {
+        if (ncur >= target) break;
+        /* gain of splitting each cell that can be split */
+        int total_gain = 0, nexp = 0;
+        qt_cell tmp[4];
+        int* scratch = inxt;
+        for (int c = 0; c < ncur; c++) {
+            if (cur[c].count <= 1) continue;
+            int f = 0;
+            total_gain += qt_split(cand, &cur[c], icur, scratch, &f, tmp) - 1;
+            nexp++;
+        }
+        if (nexp == 0) break;
+        const int all = ncur + total_gain < target;
+        int nsel = 0;
+        if (!all) {
+            /* most populated first, path order among equals: stable insertion sort of the cell numbers */
+            for (int c = 0; c < ncur; c++) {
+                if (cur[c].count <= 1) continue;
+                int j = nsel++;
+                while (j > 0 && cur[order[j - 1]].count < cur[c].count) { order[j] = order[j - 1]; j--; }
+                order[j] = c;
+            }
+            int have = ncur, take = 0;
+            for (; take < nsel && have < target; take++) {
+                int f = 0;
+                have += qt_split(cand, &cur[order[take]], icur, scratch, &f, tmp) - 1;
+            }
+            nsel = take;
+        }
+        /* next generation, in path order */
+        int nn = 0, f = 0;
+        for (int c = 0; c < ncur; c++) {
+            int split = cur[c].count > 1 && all;
+            if (!all) for (int j = 0; j < nsel; j++) if (order[j] == c) split = 1;
+            if (split) {
+                nn += qt_split(cand, &cur[c], icur, inxt, &f, nxt + nn);
+            } else {
+                qt_cell k = cur[c];
+                k.begin = f;
+                for (int j = 0; j < cur[c].count; j++) inxt[f++] = icur[cur[c].begin + j];
+                nxt[nn++] = k;
+            }
+        }
+        { qt_cell* t = cur; cur = nxt; nxt = t; int* ti = icur; icur = inxt; inxt = ti; }
+        ncur = nn;
+        if (!all) break;
+    }
+    /* the best survivor of every cell */
+    int nwin = 0;
+    for (int c = 0; c < ncur; c++) {
+        int b = icur[cur[c].begin];
+        for (int j = 1; j < cur[c].count; j++) { const int i = icur[cur[c].begin + j]; if (qt_better(cand, i, b)) b = i; }
+        order[nwin++] = b;
+    }
+    if (nwin > target) {
+        for (int a = 1; a < nwin; a++) {       /* insertion sort by (score desc, y asc, x asc) */
+            const int v = order[a];
+            int j = a;
+            while (j > 0 && qt_better(cand, v, order[j - 1])) { order[j] = order[j - 1]; j--; }
+            order[j] = v;
+        }
+        nwin = target;
+    }
+    for (int a = 0; a < nwin; a++) keep[order[a]] = 1;
+    free(cells); free(idx); free(order);
+    return ORC_OK;
+}
+
 /* cv::ORB::detectAndCompute(image, noArray(), keypoints, descriptors)
  * (reference: src/frame/detector.cpp:11).  Per level: FAST with NMS on the
  * unblurred level, drop keypoints within edge_threshold of the border, keep the
@@ -376,6 +517,12 @@ int orc_detect_and_compute(const orc_params* p, const uint8_t* img, int w, int h
 
 int orc_detect_and_compute_grid(const orc_params* p, int grid_cell, const uint8_t* img, int w, int h, int stride,
                                 orc_keypoint* kps, uint8_t* desc, int capacity, int* n) {
+    return orc_detect_and_compute_ex(p, grid_cell, 0, img, w, h, stride, kps, desc, capacity, n);
+}
+
+int orc_detect_and_compute_ex(const orc_params* p, int grid_cell, int quadtree, const uint8_t* img, int w, int h,
+                              int stride, orc_keypoint* kps, uint8_t* desc, int capacity, int* n) {
+    if (grid_cell > 0 && quadtree) return ORC_ERR_ARG;
     int ws[ORC_MAX_LEVELS], hs[ORC_MAX_LEVELS], quotas[ORC_MAX_LEVELS];
     if (!n) return ORC_ERR_ARG;
     *n = 0;
@@ -443,7 +590,21 @@ int orc_detect_and_compute_grid(const orc_params* p, int grid_cell, const uint8_
         /* KeyPointsFilter::retainBest(quota): cut at the quota-th best score, keep ties */
         int cut = 0;
         int quota = quotas[l];
-        if (kept > quota) {
+        if (quadtree && kept > quota) {
+            /* option beyond the reference: the quadtree distribution takes the place of the cut */
+            uint8_t* keepf = (uint8_t*)malloc((size_t)kept);
+            if (!keepf) { free(pyr); free(blur); free(cand); return ORC_ERR_NOMEM; }
+            rc = orc_quadtree_select(cand, kept, edge, edge, lw - edge, lh - edge, quota, keepf);
+            if (rc) { free(keepf); free(pyr); free(blur); free(cand); return rc; }
+            int k2 = 0;
+            for (int i = 0; i < kept; i++) {
+                if (!keepf[i]) continue;
+                cand[3 * k2] = cand[3 * i]; cand[3 * k2 + 1] = cand[3 * i + 1]; cand[3 * k2 + 2] = cand[3 * i + 2];
+                k2++;
+            }
+            kept = k2;
+            free(keepf);
+        } else if (kept > quota) {
             if (quota == 0) kept = 0;
             else {
                 int hist[256];

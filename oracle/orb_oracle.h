@@ -112,6 +112,11 @@ int orc_detect_and_compute(const orc_params* p, const uint8_t* img, int w, int h
  * and after the border filter, only the best NMS survivor of every grid_cell x
  * grid_cell cell (cells anchored at the level origin; highest score, first in raster
  * order among equals) before the per-level quota is applied.  grid_cell 0 = off. */
+int orc_detect_and_compute_ex(const orc_params* p, int grid_cell, int quadtree, const uint8_t* img, int w, int h,
+                              int stride, orc_keypoint* kps, uint8_t* desc, int capacity, int* n);
+/* Quadtree distribution of one level's survivors with an exact target count (option beyond the
+ * reference; see orb_oracle.c).  cand[3 i] = x, y, score inside [rx0, rx1) x [ry0, ry1). */
+int orc_quadtree_select(const int32_t* cand, int n, int rx0, int ry0, int rx1, int ry1, int target, uint8_t* keep);
 int orc_detect_and_compute_grid(const orc_params* p, int grid_cell, const uint8_t* img, int w, int h, int stride,
                                 orc_keypoint* kps, uint8_t* desc, int capacity, int* n);
 

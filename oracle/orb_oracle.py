@@ -198,7 +198,17 @@ def brief_descriptor(blurred, cx, cy, angle_deg):
     return d
 
 
-def detect_and_compute(p, img, capacity=None, grid_cell=0):
+def quadtree_select(cand, region, target):
+    """cand: [n, 3] int32 (x, y, score); region = (x0, y0, x1, y1).  Returns the keep flags."""
+    cand = np.ascontiguousarray(cand, np.int32).reshape(-1, 3)
+    keep = np.zeros(len(cand), np.uint8)
+    rc = lib().orc_quadtree_select(_p(cand), len(cand), int(region[0]), int(region[1]), int(region[2]), int(region[3]),
+                                   int(target), _p(keep))
+    if rc: raise ValueError("orc_quadtree_select rc=%d" % rc)
+    return keep.astype(bool)
+
+
+def detect_and_compute(p, img, capacity=None, grid_cell=0, quadtree=False):
     img = _img(img)
     h, w = img.shape
     if capacity is None:
@@ -207,8 +217,8 @@ def detect_and_compute(p, img, capacity=None, grid_cell=0):
         kps = np.zeros(capacity, KEYPOINT_DTYPE)
         desc = np.zeros((capacity, 32), np.uint8)
         n = C.c_int(0)
-        rc = lib().orc_detect_and_compute_grid(C.byref(p), int(grid_cell), _p(img), w, h, img.strides[0],
-                                               _p(kps), _p(desc), capacity, C.byref(n))
+        rc = lib().orc_detect_and_compute_ex(C.byref(p), int(grid_cell), int(bool(quadtree)), _p(img), w, h,
+                                             img.strides[0], _p(kps), _p(desc), capacity, C.byref(n))
         if rc == ERR_CAPACITY:
             capacity = n.value
             continue

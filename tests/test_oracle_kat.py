@@ -632,3 +632,125 @@ def test_frontend_grey_and_linear_resize_known_answers(oracle):
     out = oracle.frontend(bgr, 96)
     assert out.shape == (54, 96)
     assert np.array_equal(out, oracle.resize_linear(oracle.bgr2gray(bgr), np.float32(96) / np.float32(128)))
+
+
+# ---------------------------------------------------------------------------
+# Quadtree distribution (option beyond the reference): the oracle walks an explicit tree; this
+# model gets the same cells from sorted path codes, the form the GPU kernel uses.
+# ---------------------------------------------------------------------------
+def _quadtree_model(cand, region, target):
+    cand = np.asarray(cand, np.int64).reshape(-1, 3)
+    n = len(cand)
+    keep = np.zeros(n, bool)
+    if n <= target:
+        keep[:] = True
+        return keep
+    if target == 0:
+        return keep
+    rx0, ry0, rx1, ry1 = region
+    W, H = rx1 - rx0, ry1 - ry0
+    nini = max(1, (2 * W + H) // (2 * H))
+    rw = -(-W // nini)
+    dmax = 0
+    while (1 << dmax) < max(rw, H):
+        dmax += 1
+    codes = []
+    for x, y, _ in cand:
+        root = (x - rx0) // rw
+        x0, x1, y0, y1 = rx0 + root * rw, min(rx0 + (root + 1) * rw, rx1), ry0, ry1
+        code = root
+        for _d in range(dmax):
+            mx, my = x0 + (x1 - x0 + 1) // 2, y0 + (y1 - y0 + 1) // 2
+            q = (int(y >= my) << 1) | int(x >= mx)
+            code = (code << 2) | q
+            x0, x1 = (mx, x1) if x >= mx else (x0, mx)
+            y0, y1 = (my, y1) if y >= my else (y0, my)
+        codes.append(code)
+    codes = np.array(codes)
+    order = np.argsort(codes, kind="stable")
+    sc = codes[order]
+    # digits shared with the predecessor (digit 0 = the root index)
+    common = np.zeros(n, np.int64)
+    for i in range(1, n):
+        c = 0
+        for d in range(dmax + 1):
+            if (sc[i] >> (2 * (dmax - d))) != (sc[i - 1] >> (2 * (dmax - d))):
+                break
+            c += 1
+        common[i] = c
+    cnt = [1 + int((common[1:] <= d).sum()) for d in range(dmax + 1)]
+    d = next(d for d in range(dmax + 1) if cnt[d] >= target)
+    D = max(d - 1, 0)
+    expanded_start = set()
+    if d > 0:
+        starts = [i for i in range(n) if i == 0 or common[i] <= D]
+        cells = []
+        for k, s0 in enumerate(starts):
+            e0 = starts[k + 1] if k + 1 < len(starts) else n
+            pop = e0 - s0
+            gain = int((common[s0 + 1:e0] == D + 1).sum())
+            if pop > 1:
+                cells.append((-pop, k, s0, gain))
+        have = cnt[D]
+        for _pop, _k, s0, gain in sorted(cells):
+            if have >= target:
+                break
+            have += gain
+            expanded_start.add(s0)
+    # nodes
+    winners = []
+    cell_start = 0
+    node = []
+    def flush():
+        if node:
+            winners.append(min(node, key=lambda i: (-cand[i][2], cand[i][1], cand[i][0])))
+    for i in range(n):
+        if i == 0 or common[i] <= D:
+            cell_start = i
+        new_node = i == 0 or common[i] <= D or (common[i] == D + 1 and cell_start in expanded_start)
+        if new_node:
+            flush()
+            node = []
+        node.append(order[i])
+    flush()
+    winners.sort(key=lambda i: (-cand[i][2], cand[i][1], cand[i][0]))
+    keep[winners[:target]] = True
+    return keep
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_quadtree_select_oracle_equals_sorted_code_model(oracle, seed):
+    rng = np.random.default_rng(seed)
+    W, H = [(578, 418), (117, 72), (300, 37), (64, 64), (33, 130), (1000, 90)][seed % 6]
+    rx0, ry0 = 31, 31
+    region = (rx0, ry0, rx0 + W, ry0 + H)
+    n = int(rng.integers(2, min(W * H // 3, 1500)))
+    if seed % 3 == 0:      # clustered
+        pts = np.clip(rng.normal([W * 0.3, H * 0.6], [W * 0.08, H * 0.1], (4 * n, 2)), 0, [W - 1, H - 1]).astype(int)
+    else:
+        pts = np.stack([rng.integers(0, W, 4 * n), rng.integers(0, H, 4 * n)], 1)
+    pts = np.unique(pts, axis=0)[:n]
+    rng.shuffle(pts)
+    cand = np.concatenate([pts + [rx0, ry0], rng.integers(20, 60 if seed % 2 else 255, (len(pts), 1))], 1).astype(np.int32)
+    for target in (0, 1, 2, 7, len(cand) // 3, len(cand) - 1, len(cand), len(cand) + 5):
+        got = oracle.quadtree_select(cand, region, target)
+        assert np.array_equal(got, _quadtree_model(cand, region, target)), (seed, target)
+        assert got.sum() == min(target, len(cand))
+
+
+def test_quadtree_select_known_answers(oracle):
+    # 8 x 8 region, target 4: the four quadrants each keep their best survivor
+    cand = np.array([[0, 0, 30], [1, 1, 40], [6, 1, 25], [1, 6, 50], [2, 6, 50], [7, 7, 21], [6, 6, 22]], np.int32)
+    keep = oracle.quadtree_select(cand, (0, 0, 8, 8), 4)
+    assert keep.tolist() == [False, True, True, True, False, False, True]
+    # target 5: three quadrants hold two survivors; in path order the upper-left one is split first
+    # (both of its survivors fall into one child: nothing gained), then the lower-left one, whose
+    # survivors (1, 6) and (2, 6) separate: five cells
+    keep = oracle.quadtree_select(cand, (0, 0, 8, 8), 5)
+    assert keep.tolist() == [False, True, True, True, True, False, True]
+    # spreading beats score: a cluster of strong corners cannot take every slot
+    cluster = [[10 + i % 5, 10 + i // 5, 200] for i in range(25)]
+    lone = [[50, 50, 21], [50, 12, 22], [12, 50, 23]]
+    cand = np.array(cluster + lone, np.int32)
+    keep = oracle.quadtree_select(cand, (0, 0, 64, 64), 4)
+    assert keep[25:].all() and keep[:25].sum() == 1
