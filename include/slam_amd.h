@@ -136,6 +136,21 @@ int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_t* d_images
  * (the state after create) switches it off.  Applies to every later extract call. */
 int slam_amd_extractor_set_grid(slam_amd_extractor* ex, int cell);
 
+/* Quadtree distribution of keypoints with an exact per-level count -- not in the reference
+ * either (it is ORB-SLAM's DistributeOctTree made deterministic).  on = 1: a level whose NMS
+ * survivors (after the border filter) exceed its quota keeps exactly the quota, chosen as
+ * follows.  The region [edge, w - edge) x [edge, h - edge) is cut into max(1, round(W / H))
+ * root cells side by side; a cell splits at x0 + ceil(w / 2), y0 + ceil(h / 2), empty children
+ * are dropped, cells are ordered by path (root, then quadrant 2 * lower + right per split).
+ * While splitting every cell with more than one survivor still leaves fewer cells than the
+ * quota, all are split; in the last round they are split one by one, most populated first
+ * (path order among equals), until the quota is reached.  Every cell keeps its best survivor
+ * (highest score, then lowest y, then lowest x); if that is more than the quota, the best
+ * quota of them stay.  Levels with no more survivors than the quota, or with more than 8192,
+ * are selected as without the option.  Excludes the grid option; levels up to 4096 pixels
+ * per side.  on = 0 (the state after create) switches it off. */
+int slam_amd_extractor_set_quadtree(slam_amd_extractor* ex, int on);
+
 /* Copies one level of frame `frame` of the last batch to the host (widths[l]
  * columns, heights[l] rows, host_stride bytes per row): the unblurred pyramid
  * level, or the 7x7-blurred level the descriptors are sampled from.  For tests. */

@@ -147,6 +147,14 @@ public:
         if (ex_) check(slam_amd_extractor_set_grid(ex_, cell));
     }
 
+    // Not in the reference either: quadtree distribution with an exact per-level count
+    // (slam_amd_extractor_set_quadtree); excludes the grid option.
+    void setQuadtree(bool on) {
+        if (on && grid_cell_) throw Error(SLAM_AMD_ERR_ARG, "the grid and the quadtree distribution exclude each other");
+        quadtree_ = on;
+        if (ex_) check(slam_amd_extractor_set_quadtree(ex_, on ? 1 : 0));
+    }
+
     // reference: include/frame/detector.hpp:35-36
     int getLevels() const { return params_.nlevels; }
     double getScaleFactor() const { return static_cast<double>(params_.scale_factor); }
@@ -160,6 +168,7 @@ private:
         if (max_keypoints_ == 0) max_keypoints_ = std::max(4 * params_.nfeatures, 4096);
         check(slam_amd_extractor_create(&params_, w, h, 1, max_keypoints_, device_, &ex_));
         check(slam_amd_extractor_set_grid(ex_, grid_cell_));
+        check(slam_amd_extractor_set_quadtree(ex_, quadtree_ ? 1 : 0));
         width_ = w;
         height_ = h;
     }
@@ -168,6 +177,7 @@ private:
     slam_amd_extractor* ex_ = nullptr;
     int width_ = 0, height_ = 0, max_keypoints_ = 0;
     int grid_cell_ = 0;
+    bool quadtree_ = false;
 };
 
 // ---------------------------------------------------------------------------

@@ -27,6 +27,7 @@ EXPORTS = [
     "slam_amd_version", "slam_amd_status_string", "slam_amd_last_error", "slam_amd_device_count",
     "slam_amd_default_orb_params",
     "slam_amd_extractor_create", "slam_amd_extractor_destroy", "slam_amd_extractor_levels", "slam_amd_extractor_set_grid",
+    "slam_amd_extractor_set_quadtree",
     "slam_amd_extract", "slam_amd_extract_fetch", "slam_amd_extract_batch_async", "slam_amd_extractor_debug_level",
     "slam_amd_extractor_debug_blurred_level", "slam_amd_extractor_debug_set_select_cache",
     "slam_amd_matcher_create", "slam_amd_matcher_destroy", "slam_amd_matcher_reserve",
@@ -111,6 +112,7 @@ def lib():
         l.slam_amd_extractor_destroy.argtypes = [C.c_void_p]
         l.slam_amd_extractor_levels.argtypes = [C.c_void_p] + [C.c_void_p] * 5
         l.slam_amd_extractor_set_grid.argtypes = [C.c_void_p, C.c_int]
+        l.slam_amd_extractor_set_quadtree.argtypes = [C.c_void_p, C.c_int]
         l.slam_amd_extractor_debug_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         l.slam_amd_extractor_debug_blurred_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         l.slam_amd_extractor_debug_set_select_cache.argtypes = [C.c_void_p, C.c_int]
@@ -316,6 +318,10 @@ class Extractor:
     def set_grid(self, cell):
         """Grid distribution of keypoints (not in the reference): cell 8, 16 or 32; 0 = off."""
         check(lib().slam_amd_extractor_set_grid(self._h, cell))
+
+    def set_quadtree(self, on):
+        """Quadtree distribution with an exact per-level count (not in the reference); False = off."""
+        check(lib().slam_amd_extractor_set_quadtree(self._h, int(bool(on))))
 
     def levels(self):
         n = C.c_int(0)

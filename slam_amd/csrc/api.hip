@@ -87,6 +87,7 @@ using namespace sa;
 // =============================================================================
 struct slam_amd_extractor {
     int grid_shift = 0;                // log2 of the grid-distribution cell, 0 = off (the reference)
+    int quadtree = 0;                  // 1: quadtree distribution with an exact per-level count (not in the reference)
     slam_amd_orb_params params;
     int width = 0, height = 0, max_batch = 0, max_keypoints = 0, device = 0;
     PyrGeom g;
@@ -488,7 +489,7 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     { ProfScope ps(kStageFast, st); if ((rc = launch_fast(fa, batch, st))) return rc; }
     SelectCompactArgs sc;
     sc.hist = ex->hist.as<unsigned>(); sc.tilecount = ex->tilecount.as<unsigned>(); sc.tilelist = ex->tilelist.as<uint32_t>();
-    sc.keycap = ex->select_keycap; sc.sel = ex->sel.as<FrameSelect>(); sc.d_count = d_count;
+    sc.keycap = ex->select_keycap; sc.quadtree = ex->quadtree; sc.sel = ex->sel.as<FrameSelect>(); sc.d_count = d_count;
     sc.kp = d_kp; sc.kpxy = ex->kpxy.as<uint32_t>(); sc.capacity = capacity; sc.g = g;
     { ProfScope ps(kStageSelect, st); if ((rc = launch_select_compact(sc, batch, st))) return rc; }
     DescribeArgs da;
@@ -575,7 +576,30 @@ extern "C" int slam_amd_extractor_set_grid(slam_amd_extractor* ex, int cell) {
     if (!ex) SA_FAIL(SLAM_AMD_ERR_ARG, "extractor is null");
     if (cell != 0 && cell != 8 && cell != 16 && cell != 32)
         SA_FAIL(SLAM_AMD_ERR_ARG, "grid cell must be 0 (off), 8, 16 or 32");
+    if (cell && ex->quadtree) SA_FAIL(SLAM_AMD_ERR_ARG, "the grid and the quadtree distribution exclude each other");
     ex->grid_shift = cell == 8 ? 3 : cell == 16 ? 4 : cell == 32 ? 5 : 0;
+    return SLAM_AMD_OK;
+}
+
+extern "C" int slam_amd_extractor_set_quadtree(slam_amd_extractor* ex, int on) {
+    if (!ex) SA_FAIL(SLAM_AMD_ERR_ARG, "extractor is null");
+    if (on && ex->grid_shift) SA_FAIL(SLAM_AMD_ERR_ARG, "the grid and the quadtree distribution exclude each other");
+    if (on) {
+        // path codes are 32 bits (root index, then two bits per split) and positions 12 bits per axis
+        const PyrGeom& g = ex->g;
+        for (int l = 0; l < g.nlevels; l++) {
+            const int W = g.lv[l].w - 2 * g.edge, H = g.lv[l].h - 2 * g.edge;
+            if (W <= 0 || H <= 0) continue;
+            if (g.lv[l].w > 4096 || g.lv[l].h > 4096)
+                SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "quadtree distribution: levels larger than 4096 pixels per side");
+            const int nini = std::max(1, (2 * W + H) / (2 * H)), rw = (W + nini - 1) / nini;
+            int dmax = 0;
+            while ((1 << dmax) < std::max(rw, H)) dmax++;
+            if (2 * dmax >= 32 || ((long long)(nini - 1) >> (32 - 2 * dmax)) != 0)
+                SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "quadtree distribution: image too elongated for 32-bit path codes");
+        }
+    }
+    ex->quadtree = on ? 1 : 0;
     return SLAM_AMD_OK;
 }
 

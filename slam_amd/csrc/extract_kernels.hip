@@ -481,21 +481,18 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
 constexpr int kSelTileChunk = 4096;   // tiles whose counts are held in LDS at a time
 constexpr int kSelKeyCap = 4096;      // kept survivors ranked from LDS
 
-__global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs a) {
-    __shared__ int s_cut[kMaxLevels], s_cnt[kMaxLevels];
-    __shared__ unsigned s_wave[16];
-    __shared__ unsigned s_pref[kSelTileChunk + 1];
-    __shared__ __align__(16) unsigned s_key[kSelKeyCap];
-    __shared__ uint8_t s_score[kSelKeyCap];
-    __shared__ unsigned s_n;
-    const int b = blockIdx.x / a.g.nlevels;
-    const int my_level = blockIdx.x - b * a.g.nlevels;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_n = 0;
+constexpr int kQtCap = 8192;          // survivors of one level the quadtree kernel sorts in LDS
+
+// Selection of every level up to my_level of frame b, one wave per level: cut score and kept
+// count of KeyPointsFilter::retainBest from the score histogram (lane owns bins 4 lane ..
+// 4 lane + 3, suffix sums over the bins).  With the quadtree option a level that holds more
+// survivors than its quota (and no more than the quadtree kernel sorts) keeps exactly the quota
+// and is marked mode 1: the quadtree kernel writes it, the plain kernel skips it.
+__device__ __forceinline__ void level_selection(const SelectCompactArgs& a, int b, int my_level, int wave, int lane,
+                                                int* s_cut, int* s_cnt, int* s_mode) {
     if (wave <= my_level) {
         const int l = wave;
         const unsigned* h = a.hist + ((size_t)b * a.g.nlevels + l) * 256;
-        // lane owns bins 4*lane .. 4*lane+3; suffix sums over bins
         const unsigned v0 = h[4 * lane], v1 = h[4 * lane + 1], v2 = h[4 * lane + 2], v3 = h[4 * lane + 3];
         const unsigned own = v0 + v1 + v2 + v3;
         unsigned suf = own;
@@ -508,10 +505,12 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs 
         const unsigned s3 = above + v3, s2 = s3 + v2, s1 = s2 + v1, s0 = s1 + v0;
         const unsigned total = __shfl(suf, 0, 64);
         const unsigned quota = (unsigned)a.g.lv[l].quota;
-        int cut = 1, cnt = (int)total;
+        int cut = 1, cnt = (int)total, mode = 0;
         if (total > quota) {
             if (quota == 0) {
                 cut = 256; cnt = 0;
+            } else if (a.quadtree && total <= (unsigned)kQtCap) {
+                mode = 1; cnt = (int)quota;
             } else {
                 // largest bin c with suffix(c) >= quota; ties at the cut are all kept
                 int best = -1; unsigned bc = 0;
@@ -525,8 +524,22 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs 
                 cnt = (int)__shfl(bc, top, 64);
             }
         }
-        if (lane == 0) { s_cut[l] = cut; s_cnt[l] = cnt; }
+        if (lane == 0) { s_cut[l] = cut; s_cnt[l] = cnt; s_mode[l] = mode; }
     }
+}
+
+__global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs a) {
+    __shared__ int s_cut[kMaxLevels], s_cnt[kMaxLevels], s_mode[kMaxLevels];
+    __shared__ unsigned s_wave[16];
+    __shared__ unsigned s_pref[kSelTileChunk + 1];
+    __shared__ __align__(16) unsigned s_key[kSelKeyCap];
+    __shared__ uint8_t s_score[kSelKeyCap];
+    __shared__ unsigned s_n;
+    const int b = blockIdx.x / a.g.nlevels;
+    const int my_level = blockIdx.x - b * a.g.nlevels;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_n = 0;
+    level_selection(a, b, my_level, wave, lane, s_cut, s_cnt, s_mode);
     __syncthreads();
 
     const int l = my_level;
@@ -565,7 +578,7 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs 
         return (y << 14) | x;
     };
 
-    if (kept > 0 && cut < 256) {
+    if (kept > 0 && cut < 256 && s_mode[l] == 0) {
         for (int chunk0 = 0; chunk0 < ntl; chunk0 += kSelTileChunk) {
             const int nt = min(kSelTileChunk, ntl - chunk0);
             // exclusive prefix of the tiles' survivor counts: four tiles per thread
@@ -660,6 +673,213 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs 
         fs.pad[0] = fs.pad[1] = fs.pad[2] = 0;
         a.sel[b] = fs;
         if (a.d_count) a.d_count[b] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Quadtree distribution (option beyond the reference; the CPU oracle walks an explicit tree).
+// One workgroup per (frame, level) whose survivors exceed the quota.  Every survivor gets the
+// path code of its finest cell: root index, then one quadrant digit (2 lower + right) per split,
+// cells split at x0 + ceil(w / 2), y0 + ceil(h / 2).  Sorted by code, the cells of every depth
+// are runs, and the number of leading digits a survivor shares with its predecessor says at
+// which depth the two separate: cells(d) = 1 + #{shared <= d}.  The tree grows whole levels
+// while that stays below the target; in the last round cells are split one by one, most
+// populated first (path order among equals), until the target is reached.  Every cell keeps
+// its best survivor; if that is more than the target, the best `target` stay.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void quadtree_select_kernel(SelectCompactArgs a) {
+    __shared__ int s_cut[kMaxLevels], s_cnt[kMaxLevels], s_mode[kMaxLevels];
+    __shared__ unsigned long long s_key[kQtCap];   // code << 32 | score << 24 | y << 12 | x
+    __shared__ unsigned s_aux[kQtCap];             // cell candidates, then the winners
+    __shared__ uint8_t s_mark[kQtCap];             // bit 0: first of a node; bit 1: first of a split cell
+    __shared__ unsigned s_hc[32];
+    __shared__ unsigned s_n, s_nc, s_nw;
+    const int b = blockIdx.x / a.g.nlevels;
+    const int l = blockIdx.x - b * a.g.nlevels;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_n = 0; s_nc = 0; s_nw = 0; }
+    if (tid < 32) s_hc[tid] = 0;
+    level_selection(a, b, l, wave, lane, s_cut, s_cnt, s_mode);
+    __syncthreads();
+    if (s_mode[l] != 1) return;
+    const LevelGeom& L = a.g.lv[l];
+    const int target = s_cnt[l];
+    int base = 0;
+    for (int i = 0; i < l; i++) base += s_cnt[i];
+    // geometry of the tree
+    const int edge = a.g.edge;
+    const int rx0 = edge, ry0 = edge, rx1 = L.w - edge, ry1 = L.h - edge;
+    const int W = rx1 - rx0, H = ry1 - ry0;
+    const int nini = max(1, (2 * W + H) / (2 * H));
+    const int rw = (W + nini - 1) / nini;
+    int dmax = 0;
+    while ((1 << dmax) < max(rw, H)) dmax++;
+    // ---- gather the level's survivors with their path codes ----
+    const int tiles_x = L.tiles_x, ntl = tiles_x * div_up_dev(L.h, kFastTileH);
+    const unsigned* tcount = a.tilecount + (size_t)b * a.g.total_tiles + L.tile_base;
+    const uint32_t* tlist = a.tilelist + ((size_t)b * a.g.total_tiles + L.tile_base) * kTileListCap;
+    for (int t = wave; t < ntl; t += 16) {
+        const unsigned nt = min(tcount[t], (unsigned)kTileListCap);
+        const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+        for (unsigned e0 = 0; e0 < nt; e0 += 64) {
+            const unsigned e = e0 + lane;
+            const bool on = e < nt;
+            unsigned long long key = 0;
+            if (on) {
+                const uint32_t ent = tlist[(size_t)t * kTileListCap + e];
+                const int x = txi * kFastTileW + (int)(ent & 63u), y = tyi * kFastTileH + (int)((ent >> 6) & 31u);
+                const int root = (x - rx0) / rw;
+                int x0 = rx0 + root * rw, x1 = min(x0 + rw, rx1), y0 = ry0, y1 = ry1;
+                unsigned code = (unsigned)root;
+                for (int d = 0; d < dmax; d++) {
+                    const int mx = x0 + (x1 - x0 + 1) / 2, my = y0 + (y1 - y0 + 1) / 2;
+                    const bool right = x >= mx, lower = y >= my;
+                    code = (code << 2) | ((unsigned)lower << 1) | (unsigned)right;
+                    if (right) x0 = mx; else x1 = mx;
+                    if (lower) y0 = my; else y1 = my;
+                }
+                key = ((unsigned long long)code << 32) | ((unsigned long long)(ent >> 16) << 24) | ((unsigned)y << 12) | (unsigned)x;
+            }
+            const unsigned long long m = __ballot(on);
+            unsigned slot0 = 0;
+            if (lane == 0) slot0 = atomicAdd(&s_n, (unsigned)__builtin_popcountll(m));
+            slot0 = (unsigned)__builtin_amdgcn_readfirstlane((int)slot0);
+            if (on && slot0 + lane < (unsigned)kQtCap) s_key[slot0 + lane] = key;
+        }
+    }
+    __syncthreads();
+    const int S = (int)min(s_n, (unsigned)kQtCap);
+    int n2 = 1;
+    while (n2 < S) n2 <<= 1;
+    for (int i = S + tid; i < n2; i += 1024) s_key[i] = ~0ull;
+    __syncthreads();
+    // ---- bitonic sort, ascending ----
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < n2 / 2; p += 1024) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));   // bit j of i is 0
+                const int q = i | j;
+                const unsigned long long ki = s_key[i], kq = s_key[q];
+                const bool up = (i & k) == 0;
+                if ((ki > kq) == up) { s_key[i] = kq; s_key[q] = ki; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- digits shared with the predecessor (digit 0 = root index), cells per depth ----
+    auto shared_digits = [&](int i) -> int {
+        const unsigned x = (unsigned)(s_key[i] >> 32) ^ (unsigned)(s_key[i - 1] >> 32);
+        if (dmax < 16 && (x >> (2 * dmax)) != 0) return 0;
+        const int hb = 31 - __builtin_clz(x);         // codes differ: positions are distinct
+        return 1 + (dmax - 1 - (hb >> 1));
+    };
+    for (int i = 1 + tid; i < S; i += 1024) atomicAdd(&s_hc[shared_digits(i)], 1u);
+    __syncthreads();
+    int dstop = dmax, cells_d = 0, cells_prev = 0;
+    {
+        int cells = 1;
+        for (int d = 0; d <= dmax; d++) {
+            cells += (int)s_hc[d];
+            if (cells >= target) { dstop = d; cells_d = cells; break; }
+            cells_prev = cells;
+        }
+    }
+    (void)cells_d;
+    const int D = max(dstop - 1, 0);
+    const bool careful = dstop > 0;
+    const int need = target - cells_prev;           // cells still missing at depth D (careful round)
+    // ---- careful round: cells of depth D that gain by a split, ordered by population ----
+    for (int i = tid; i < S; i += 1024) s_mark[i] = 0;
+    __syncthreads();
+    if (careful) {
+        for (int i = tid; i < S; i += 1024) {
+            if (i != 0 && shared_digits(i) > D) continue;      // not the first of a cell
+            int pop = 1, gain = 0;
+            for (int j = i + 1; j < S; j++) {
+                const int c = shared_digits(j);
+                if (c <= D) break;
+                pop++;
+                gain += c == D + 1;
+            }
+            if (gain > 0) {
+                const unsigned slot = atomicAdd(&s_nc, 1u);
+                // order: population descending, then path order; 13 bits each for index and gain
+                s_aux[slot] = ((unsigned)pop << 18) | ((unsigned)(kQtCap - 1 - i) << 5) | (unsigned)min(gain, 3);
+            }
+        }
+    }
+    __syncthreads();
+    if (careful) {
+        const int nc = (int)s_nc;
+        for (int c = tid; c < nc; c += 1024) {
+            const unsigned me = s_aux[c];
+            int before = 0;      // cells gained by the candidates ahead of this one
+            for (int o = 0; o < nc; o++) {
+                const unsigned v = s_aux[o];
+                before += ((v >> 5) > (me >> 5)) ? (int)(v & 31u) : 0;
+            }
+            if (before < need) s_mark[kQtCap - 1 - (int)((me >> 5) & 8191u)] = 2;
+        }
+    }
+    __syncthreads();
+    // ---- nodes: first survivor of every final cell ----
+    for (int i = tid; i < S; i += 1024) {
+        if (i != 0 && shared_digits(i) > D) continue;
+        const bool split = (s_mark[i] & 2) != 0;
+        s_mark[i] |= 1;      // every byte of s_mark has one writer per phase
+        if (!split) continue;
+        for (int j = i + 1; j < S; j++) {
+            const int c = shared_digits(j);
+            if (c <= D) break;
+            if (c == D + 1) s_mark[j] = 1;
+        }
+    }
+    __syncthreads();
+    // ---- winner of every node: highest score, then lowest y, then lowest x ----
+    for (int i = tid; i < S; i += 1024) {
+        if (!(s_mark[i] & 1)) continue;
+        unsigned bestw = 0;
+        for (int j = i; j < S; j++) {
+            if (j > i && (s_mark[j] & 1)) break;
+            const unsigned pay = (unsigned)s_key[j];
+            const unsigned w = (pay & 0xff000000u) | (0x00ffffffu - (pay & 0x00ffffffu));
+            bestw = max(bestw, w);
+        }
+        s_aux[atomicAdd(&s_nw, 1u)] = bestw;      // the candidate list is dead
+    }
+    __syncthreads();
+    // ---- at most `target` winners, written in (y, x) order ----
+    const int M = (int)s_nw;
+    slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity;
+    uint32_t* kpxy = a.kpxy + (size_t)b * a.capacity;
+    unsigned* s_kept = reinterpret_cast<unsigned*>(s_key);      // the sorted keys are dead
+    for (int i = tid; i < M; i += 1024) {
+        const unsigned w = s_aux[i];
+        int better = 0;
+        for (int o = 0; o < M; o++) better += s_aux[o] > w;
+        // 0xffffffff sorts after every position
+        s_kept[i] = better < target ? (0x00ffffffu - (w & 0x00ffffffu)) : 0xffffffffu;
+    }
+    __syncthreads();
+    for (int i = tid; i < M; i += 1024) {
+        const unsigned yx = s_kept[i];
+        if (yx == 0xffffffffu) continue;
+        int rank = 0;
+        for (int o = 0; o < M; o++) rank += s_kept[o] < yx;
+        const int pos = base + rank;
+        if ((unsigned)pos < (unsigned)a.capacity) {
+            const unsigned x = yx & 0xfffu, y = yx >> 12;
+            slam_amd_keypoint q;
+            q.x = (float)x;
+            q.y = (float)y;
+            q.size = L.size;
+            q.angle = -1.f;
+            q.response = (float)(s_aux[i] >> 24);
+            q.octave = l;
+            q.class_id = -1;
+            kp[pos] = q;
+            kpxy[pos] = x | (y << 14) | ((uint32_t)l << 28);
+        }
     }
 }
 
@@ -990,6 +1210,10 @@ int launch_fast(const FastArgs& a0, int batch, hipStream_t st) {
 int launch_select_compact(const SelectCompactArgs& a, int batch, hipStream_t st) {
     hipLaunchKernelGGL(select_compact_kernel, dim3(batch * a.g.nlevels), dim3(1024), 0, st, a);
     SA_HIP(hipGetLastError());
+    if (a.quadtree) {
+        hipLaunchKernelGGL(quadtree_select_kernel, dim3(batch * a.g.nlevels), dim3(1024), 0, st, a);
+        SA_HIP(hipGetLastError());
+    }
     return SLAM_AMD_OK;
 }
 

@@ -46,6 +46,7 @@ struct SelectCompactArgs {
     const unsigned* tilecount;
     const uint32_t* tilelist;
     int keycap;                // kept survivors of a level ranked from LDS (<= 4096; lower in tests)
+    int quadtree;              // 1: levels over their quota keep exactly the quota, chosen by the quadtree kernel
     FrameSelect* sel;
     int32_t* d_count;          // may be null
     slam_amd_keypoint* kp;     // [batch][capacity]

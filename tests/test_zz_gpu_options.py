@@ -38,6 +38,39 @@ def test_grid_distribution_option_vs_oracle(oracle, capi, cell):
         ex.close()
 
 
+@pytest.mark.parametrize("w,h,nf,seed", [(640, 480, 2000, 1), (333, 271, 500, 9), (1241, 376, 4000, 3), (640, 480, 300, 5)])
+def test_quadtree_distribution_option_vs_oracle(oracle, capi, w, h, nf, seed):
+    """Quadtree distribution with an exact per-level count (an option the reference does not have)
+    against its oracle, which walks an explicit tree."""
+    img = synth.scene(w, h, seed=seed)
+    po = oracle.params(nfeatures=nf)
+    ex = capi.Extractor(capi.orb_params(nfeatures=nf), w, h, max_batch=1, max_keypoints=16384)
+    ex.set_quadtree(True)
+    kp_g, d_g = ex.extract(img)
+    kp_o, d_o = oracle.detect_and_compute(po, img, quadtree=True)
+    assert len(kp_g) == len(kp_o)
+    assert kp_g.tobytes() == kp_o.tobytes() and np.array_equal(d_g, d_o)
+    # exact counts: a level never keeps more than its quota, and the plain selection (ties at the
+    # cut kept) never keeps fewer
+    plain_o, _ = oracle.detect_and_compute(po, img)
+    _, _, quotas, _ = ex.levels()
+    per_level = np.bincount(kp_g["octave"], minlength=len(quotas))
+    plain_level = np.bincount(plain_o["octave"], minlength=len(quotas))
+    assert (per_level <= quotas).all() and (per_level <= plain_level).all()
+    assert (per_level[plain_level >= quotas] == quotas[plain_level >= quotas]).all()
+    assert per_level.sum() < plain_level.sum() or (plain_level <= quotas).all()
+    with pytest.raises(capi.SlamAmdError):
+        ex.set_grid(16)
+    # off again: the reference's selection
+    ex.set_quadtree(False)
+    kp_g, d_g = ex.extract(img)
+    assert kp_g.tobytes() == plain_o.tobytes()
+    ex.set_grid(16)
+    with pytest.raises(capi.SlamAmdError):
+        ex.set_quadtree(True)
+    ex.close()
+
+
 def test_outlier_flags_vs_oracle(oracle, capi):
     """Batched isOutlier (src/map/mappoint.cpp:54-101) against the oracle, flag for flag."""
     n = 5000
