@@ -250,6 +250,10 @@ static AxisPlan plan_axis(const std::vector<std::vector<int32_t>>& off, const in
     return ap;
 }
 
+// A chain buffer holds whole staged rows; the horizontal pass reads three dwords from the dword of a
+// group's first tap, up to 11 bytes past the last one it needs: 16 spare bytes.
+static size_t pyr_buffer_bytes(size_t area) { return ((area + 15) & ~(size_t)15) + 16; }
+
 struct HostGroup { int first, last, T, ntx, nty; AxisPlan ax, ay; size_t lds; };
 struct HostPyramidPlan {
     std::vector<std::vector<uint32_t>> xt, yt;   // per level
@@ -285,6 +289,9 @@ static int make_pyramid_plan(const PyrGeom& g, HostPyramidPlan& plan) {
             return true;
         };
         if (!fill(sw, dw, xo[l], xt[l]) || !fill(sh, dh, yo[l], yt[l])) SA_FAIL(SLAM_AMD_ERR_ARG, "image too large");
+        // the kernel takes the taps of four neighbouring destination columns from eight source bytes
+        for (size_t d = 0; d + 3 < xo[l].size(); d += 4)
+            if (xo[l][d + 3] - xo[l][d] > 6) SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "scale factor too large for the pyramid kernel");
     }
     // groups of consecutive levels whose regions fit the LDS budget, tiles of 32 (else 16, 8) pixels
 #ifndef SA_PYR_LDS_KB
@@ -298,7 +305,7 @@ static int make_pyramid_plan(const PyrGeom& g, HostPyramidPlan& plan) {
         out.ay = plan_axis(yo, hs, first, last, T, out.nty, false);
         const int tabcap = (std::max(out.ax.max_tab, out.ay.max_tab) + 3) & ~3;
         const size_t even = (size_t)out.ax.max_len_even * out.ay.max_len_even, odd = (size_t)out.ax.max_len_odd * out.ay.max_len_odd;
-        out.lds = (size_t)(last - first + 1) * tabcap * 8 + ((even + 15) & ~(size_t)15) + ((odd + 15) & ~(size_t)15);
+        out.lds = (size_t)(last - first + 1) * tabcap * 8 + pyr_buffer_bytes(even) + pyr_buffer_bytes(odd);
         const int widest = std::max(out.ax.max_len_even, out.ax.max_len_odd);
         return out.lds <= kLdsBudget && widest <= 1020;
     };
@@ -364,8 +371,8 @@ static int build_tables(slam_amd_extractor* ex) {
         slam_amd_extractor::PyrGroupPlan pg;
         pg.first = hg.first; pg.last = hg.last; pg.ntx = hg.ntx; pg.nty = hg.nty;
         pg.tabcap = (std::max(hg.ax.max_tab, hg.ay.max_tab) + 3) & ~3;
-        pg.buf_even = (int)(((size_t)hg.ax.max_len_even * hg.ay.max_len_even + 15) & ~(size_t)15);
-        pg.buf_odd = (int)(((size_t)hg.ax.max_len_odd * hg.ay.max_len_odd + 15) & ~(size_t)15);
+        pg.buf_even = (int)pyr_buffer_bytes((size_t)hg.ax.max_len_even * hg.ay.max_len_even);
+        pg.buf_odd = (int)pyr_buffer_bytes((size_t)hg.ax.max_len_odd * hg.ay.max_len_odd);
         pg.spanx = reinterpret_cast<const PyrSpan*>(base + o_sx[i]);
         pg.spany = reinterpret_cast<const PyrSpan*>(base + o_sy[i]);
         pg.lds_bytes = hg.lds;

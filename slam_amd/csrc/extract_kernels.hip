@@ -13,6 +13,11 @@
 #include "detmath.h"
 #include "kernels.h"
 
+// build-time experiment switch (1: describe without its global patch loads); 0 in every shipped build
+#ifndef SA_DESC_EXP
+#define SA_DESC_EXP 0
+#endif
+
 namespace sa {
 
 // ---------------------------------------------------------------------------
@@ -969,7 +974,11 @@ __device__ __forceinline__ void patch_load(PatchRegs<R, PITCH>& pr, const uint8_
 #pragma unroll
     for (int it = 0; it < PR::ITERS; it++) {
         pr.v[it] = 0;
+#if SA_DESC_EXP == 1
+        if (lr < PR::RPI && lr + it * PR::RPI < PR::ROWS && pitch < 0)
+#else
         if (lr < PR::RPI && lr + it * PR::RPI < PR::ROWS)
+#endif
             pr.v[it] = *reinterpret_cast<const uint32_t*>(base + (size_t)(it * PR::RPI) * pitch + voff);
     }
 }

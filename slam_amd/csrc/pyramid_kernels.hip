@@ -13,6 +13,12 @@
 
 namespace sa {
 
+typedef unsigned short py_us2 __attribute__((ext_vector_type(2)));
+// a.lo * b.lo + a.hi * b.hi + c on 16-bit halves
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(py_us2, a), __builtin_bit_cast(py_us2, b), c, false);
+}
+
 // floor(x / d) for 0 <= x < 256, 1 <= d < 256, by one multiplication.
 __device__ __forceinline__ int small_div(int x, int d_inv16) { return (x * d_inv16) >> 16; }
 
@@ -95,6 +101,13 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
     __syncthreads();
 
     // ---- the chain ----
+    // Thread (band of destination rows, group of four destination columns) walks down the source rows
+    // of its band.  Horizontal step per source row: the three dwords that hold the group's source
+    // bytes, the eight bytes from the first source column on moved into two registers (v_alignbyte),
+    // each pixel's two taps picked as a pair of 16-bit halves (v_perm, selector constant per thread),
+    // c0 a + c1 b as one 16-bit dot product.  The exact 16-bit sums of the last two source rows stay
+    // in registers; whenever they are the two rows a destination row reads, the vertical step forms
+    // (m0 h0 + m1 h1 + 2^15) >> 16, again one dot product per pixel, byte 2 of which is the result.
     for (int k = 1; k < slots; k++) {
         const int l = a.first + k - 1;
         const LevelGeom& L = a.g.lv[l];
@@ -109,61 +122,59 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
         const uint32_t* xt = s_xt + (k - 1) * a.tabcap;
         const uint32_t* yt = s_yt + (k - 1) * a.tabcap;
         const int inv = 65536 / n4 + 1;
-        const int q = 256 / n4, r = 256 - q * n4;
-        int row = small_div(tid, inv), c = tid - row * n4;
-        // kUnroll items per trip: every LDS read of the trip is issued before the first result is
-        // stored, so the reads of one item overlap the arithmetic of another
-        constexpr int kUnroll = 4;
-        const unsigned gbase = (unsigned)cy0 * (unsigned)L.pitch + (unsigned)cx0;   // a level is < 2^28 bytes
-        while (row < rows) {
-            int irow[kUnroll], icol[kUnroll];
-            uint4 xe[kUnroll];
-            uint32_t ye[kUnroll];
-            uint32_t t0[kUnroll][4][2], t1[kUnroll][4][2];
+        const int par = min(256 / n4, rows);            // bands side by side
+        const int rr = small_div(tid, inv), gi = tid - rr * n4;
+        if (rr < par) {
+            // destination rows of the band
+            const int ra = (rr * rows) / par, rb = ((rr + 1) * rows) / par;
+            const uint4 xe = *reinterpret_cast<const uint4*>(xt + 4 * gi);
+            const uint32_t e[4] = {xe.x, xe.y, xe.z, xe.w};
+            const unsigned first = (e[0] & 0xffffu) - (unsigned)sx0;     // byte of the first tap in a staged row
+            const unsigned shift = first & 3u;
+            unsigned sel[4], wgt[4];
 #pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-                irow[u] = row; icol[u] = c;
-                row += q; c += r;
-                if (c >= n4) { c -= n4; row++; }
+            for (int j = 0; j < 4; j++) {
+                const unsigned o = (e[j] & 0xffffu) - (e[0] & 0xffffu);  // <= 6: checked when the plan is made
+                sel[j] = o | 0x0c000c00u | ((o + 1u) << 16);
+                const unsigned c1 = e[j] >> 16;
+                wgt[j] = (256u - c1) | (c1 << 16);
             }
-#pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-                const bool on = irow[u] < rows;
-                xe[u] = *reinterpret_cast<const uint4*>(xt + 4 * (on ? icol[u] : 0));
-                ye[u] = yt[on ? irow[u] : 0];
-            }
-#pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-                const uint8_t* r0 = sbuf + __umul24((ye[u] & 0xffffu) - (unsigned)sy0, (unsigned)spitch) - sx0;
-                const uint8_t* r1 = r0 + spitch;
-                const uint32_t e[4] = {xe[u].x, xe[u].y, xe[u].z, xe[u].w};
+            const uint8_t* src = sbuf + (first & ~3u);
+            const unsigned gbase = (unsigned)cy0 * (unsigned)L.pitch + (unsigned)cx0 + 4u * (unsigned)gi;   // a level is < 2^28 bytes
+            const int gx = cx0 + 4 * gi;
+            const bool own_x = gx >= ox0 && gx < ox1;
+            int r = ra;                                                  // next destination row to write
+            uint32_t ye = yt[min(r, rows - 1)];
+            int want = (int)(ye & 0xffffu) - sy0 + 1;                    // it is complete with this source row
+            const int s_first = want - 1;
+            const int s_last = (int)(yt[max(rb, 1) - 1] & 0xffffu) - sy0 + 1;
+            uint32_t hp[4] = {0u, 0u, 0u, 0u}, hc[4] = {0u, 0u, 0u, 0u};
+            for (int sr = s_first; sr <= s_last && r < rb; sr++) {
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(src + sr * spitch);
+                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+                const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, shift), hi = __builtin_amdgcn_alignbyte(d2, d1, shift);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    // (byte reads: a 2-byte read at an odd address is legal on gfx950 but several times slower)
-                    const uint32_t xo = e[j] & 0xffffu;
-                    t0[u][j][0] = r0[xo]; t0[u][j][1] = r0[xo + 1];
-                    t1[u][j][0] = r1[xo]; t1[u][j][1] = r1[xo + 1];
+                    hp[j] = hc[j];
+                    hc[j] = dot2_u16(__builtin_amdgcn_perm(hi, lo, sel[j]), wgt[j], 0u);
                 }
-            }
+                // destination rows whose second source row this is (one at most while the scale is >= 1,
+                // several only among the clamped rows at the edge of the region)
+                while (r < rb && want == sr) {
+                    const unsigned m1 = ye >> 16, mw = (256u - m1) | (m1 << 16);
+                    uint32_t v[4];
 #pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-                if (irow[u] >= rows) continue;
-                const uint32_t m1 = ye[u] >> 16, m0 = 256u - m1;
-                const uint32_t e[4] = {xe[u].x, xe[u].y, xe[u].z, xe[u].w};
-                uint32_t packed = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t c1 = e[j] >> 16, c0 = 256u - c1;
-                    const uint32_t h0 = __umul24(t0[u][j][0], c0) + __umul24(t0[u][j][1], c1);
-                    const uint32_t h1 = __umul24(t1[u][j][0], c0) + __umul24(t1[u][j][1], c1);
-                    const uint32_t v = (__umul24(h0, m0) + __umul24(h1, m1) + 32768u) >> 16;
-                    packed |= v << (8 * j);
+                    for (int j = 0; j < 4; j++)
+                        v[j] = dot2_u16(__builtin_amdgcn_perm(hc[j], hp[j], 0x05040100u), mw, 32768u);
+                    const uint32_t packed = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020c0cu);
+                    *reinterpret_cast<uint32_t*>(dbuf + (r * n4 + gi) * 4) = packed;
+                    const int gy = cy0 + r;
+                    if (own_x && gy >= oy0 && gy < oy1)
+                        *reinterpret_cast<uint32_t*>(gdst + (gbase + __umul24((unsigned)r, (unsigned)L.pitch))) = packed;
+                    r++;
+                    ye = yt[min(r, rows - 1)];
+                    want = (int)(ye & 0xffffu) - sy0 + 1;
                 }
-                const unsigned li = __umul24((unsigned)irow[u], (unsigned)n4) + (unsigned)icol[u];
-                *reinterpret_cast<uint32_t*>(dbuf + li * 4) = packed;
-                const int gy = cy0 + irow[u], gx = cx0 + 4 * icol[u];
-                if (gy >= oy0 && gy < oy1 && gx >= ox0 && gx < ox1)
-                    *reinterpret_cast<uint32_t*>(gdst + (gbase + __umul24((unsigned)irow[u], (unsigned)L.pitch) + 4u * (unsigned)icol[u])) = packed;
             }
         }
         lds_barrier();
