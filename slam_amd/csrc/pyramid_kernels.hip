@@ -11,6 +11,11 @@
 #include "common.h"
 #include "kernels.h"
 
+// build-time experiment switch (1: staging only, 2: chain without global stores); 0 in every shipped build
+#ifndef SA_PYR_EXP
+#define SA_PYR_EXP 0
+#endif
+
 namespace sa {
 
 typedef unsigned short py_us2 __attribute__((ext_vector_type(2)));
@@ -36,6 +41,53 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
     uint8_t* buf1 = buf0 + a.buf_even;
     const int tid = threadIdx.x;
 
+    // ---- stage the source region (slot 0); columns / rows past the image stay unwritten or zero:
+    //      they are only ever read with weight 0.  All loads of a thread are issued first (up to
+    //      kStage dwords per trip; a 32-pixel tile needs one trip), the coefficient slices are
+    //      fetched while they are in flight, then the dwords go to LDS ----
+    constexpr int kStage = 16;
+    const int ls0 = a.first - 1;
+    const uint8_t* src_img;
+    int src_pitch, src_aligned;
+    if (ls0 == 0) {
+        src_img = a.src0 + (size_t)b * a.src0_frame_pitch; src_pitch = a.src0_pitch; src_aligned = a.src0_aligned;
+    } else {
+        src_img = a.pyr + (size_t)b * a.g.frame_bytes + a.g.lv[ls0].off; src_pitch = a.g.lv[ls0].pitch; src_aligned = 1;
+    }
+    const int w0 = a.g.lv[ls0].w, h0 = a.g.lv[ls0].h;
+    const int st_x0 = sx[0].c0, st_n4 = (sx[0].c1 - sx[0].c0 + 3) >> 2;
+    const int st_y0 = sy[0].c0, st_rows = min(sy[0].c1, h0) - st_y0;
+    const int st_inv = 65536 / st_n4 + 1;
+    const int st_q = 256 / st_n4, st_r = 256 - st_q * st_n4;
+    int st_row = small_div(tid, st_inv), st_c = tid - st_row * st_n4;
+    int li[kStage];
+    uint32_t sv[kStage];
+    auto stage_loads = [&]() {
+#pragma unroll
+        for (int u = 0; u < kStage; u++) {
+            li[u] = st_row < st_rows ? st_row * st_n4 + st_c : -1;
+            sv[u] = 0;
+            if (st_row < st_rows) {
+                const int x = st_x0 + 4 * st_c;
+                const uint8_t* p = src_img + (size_t)(st_y0 + st_row) * src_pitch + x;
+                if (src_aligned && x + 3 < w0) {
+                    sv[u] = *reinterpret_cast<const uint32_t*>(p);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (x + j < w0) sv[u] |= (uint32_t)p[j] << (8 * j);
+                }
+            }
+            st_row += st_q; st_c += st_r;
+            if (st_c >= st_n4) { st_c -= st_n4; st_row++; }
+        }
+    };
+    auto stage_stores = [&]() {
+#pragma unroll
+        for (int u = 0; u < kStage; u++)
+            if (li[u] >= 0) *reinterpret_cast<uint32_t*>(buf0 + li[u] * 4) = sv[u];
+    };
+    stage_loads();
     // ---- coefficient slices of every level of the group.  A slice covers the computed range,
     //      which is the needed range widened to whole dwords; the extra positions are never used,
     //      so their source indices are clamped into the source range instead of widening that too ----
@@ -53,61 +105,25 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
             s_yt[(k - 1) * a.tabcap + i] = (e & 0xffff0000u) | min(max(e & 0xffffu, ylo), yhi);
         }
     }
-    // ---- stage the source region (slot 0); columns / rows past the image stay unwritten or zero:
-    //      they are only ever read with weight 0 ----
-    {
-        const int ls = a.first - 1;
-        const uint8_t* src;
-        int pitch, aligned;
-        if (ls == 0) {
-            src = a.src0 + (size_t)b * a.src0_frame_pitch; pitch = a.src0_pitch; aligned = a.src0_aligned;
-        } else {
-            src = a.pyr + (size_t)b * a.g.frame_bytes + a.g.lv[ls].off; pitch = a.g.lv[ls].pitch; aligned = 1;
-        }
-        const int w = a.g.lv[ls].w, h = a.g.lv[ls].h;
-        const int x0 = sx[0].c0, n4 = (sx[0].c1 - sx[0].c0 + 3) >> 2;
-        const int y0 = sy[0].c0, rows = min(sy[0].c1, h) - y0;
-        const int inv = 65536 / n4 + 1;
-        const int q = 256 / n4, r = 256 - q * n4;
-        int row = small_div(tid, inv), c = tid - row * n4;
-        while (row < rows) {
-            // four dwords per trip, loads first
-            constexpr int kUnroll = 4;
-            int li[kUnroll];
-            uint32_t v[kUnroll];
-#pragma unroll
-            for (int u = 0; u < kUnroll; u++) {
-                li[u] = row < rows ? row * n4 + c : -1;
-                v[u] = 0;
-                if (row < rows) {
-                    const int x = x0 + 4 * c;
-                    const uint8_t* p = src + (size_t)(y0 + row) * pitch + x;
-                    if (aligned && x + 3 < w) {
-                        v[u] = *reinterpret_cast<const uint32_t*>(p);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (x + j < w) v[u] |= (uint32_t)p[j] << (8 * j);
-                    }
-                }
-                row += q; c += r;
-                if (c >= n4) { c -= n4; row++; }
-            }
-#pragma unroll
-            for (int u = 0; u < kUnroll; u++)
-                if (li[u] >= 0) *reinterpret_cast<uint32_t*>(buf0 + li[u] * 4) = v[u];
-        }
+    stage_stores();
+    while (st_row < st_rows) {     // larger source regions: further trips
+        stage_loads();
+        stage_stores();
     }
     __syncthreads();
+#if SA_PYR_EXP == 1
+    return;
+#endif
 
     // ---- the chain ----
-    // Thread (band of destination rows, group of four destination columns) walks down the source rows
-    // of its band.  Horizontal step per source row: the three dwords that hold the group's source
-    // bytes, the eight bytes from the first source column on moved into two registers (v_alignbyte),
-    // each pixel's two taps picked as a pair of 16-bit halves (v_perm, selector constant per thread),
-    // c0 a + c1 b as one 16-bit dot product.  The exact 16-bit sums of the last two source rows stay
-    // in registers; whenever they are the two rows a destination row reads, the vertical step forms
-    // (m0 h0 + m1 h1 + 2^15) >> 16, again one dot product per pixel, byte 2 of which is the result.
+    // Thread (destination row, group of four destination columns); the group is fixed per thread and
+    // level, the rows are taken four at a time so that all LDS reads of a trip are in flight before
+    // the first result is needed.  Horizontal step for each of the row's two source rows: the three
+    // dwords that hold the group's source bytes, the eight bytes from the first source column on moved
+    // into two registers (v_alignbyte), each pixel's two taps picked as a pair of 16-bit halves (v_perm,
+    // selector constant per thread), c0 a + c1 b as one 16-bit dot product -- exact in 16 bits.
+    // Vertical step: (m0 h0 + m1 h1 + 2^15) >> 16, again one dot product per pixel, byte 2 of which
+    // is the result.
     for (int k = 1; k < slots; k++) {
         const int l = a.first + k - 1;
         const LevelGeom& L = a.g.lv[l];
@@ -122,11 +138,9 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
         const uint32_t* xt = s_xt + (k - 1) * a.tabcap;
         const uint32_t* yt = s_yt + (k - 1) * a.tabcap;
         const int inv = 65536 / n4 + 1;
-        const int par = min(256 / n4, rows);            // bands side by side
+        const int par = 256 / n4;                       // rows side by side
         const int rr = small_div(tid, inv), gi = tid - rr * n4;
         if (rr < par) {
-            // destination rows of the band
-            const int ra = (rr * rows) / par, rb = ((rr + 1) * rows) / par;
             const uint4 xe = *reinterpret_cast<const uint4*>(xt + 4 * gi);
             const uint32_t e[4] = {xe.x, xe.y, xe.z, xe.w};
             const unsigned first = (e[0] & 0xffffu) - (unsigned)sx0;     // byte of the first tap in a staged row
@@ -143,37 +157,40 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
             const unsigned gbase = (unsigned)cy0 * (unsigned)L.pitch + (unsigned)cx0 + 4u * (unsigned)gi;   // a level is < 2^28 bytes
             const int gx = cx0 + 4 * gi;
             const bool own_x = gx >= ox0 && gx < ox1;
-            int r = ra;                                                  // next destination row to write
-            uint32_t ye = yt[min(r, rows - 1)];
-            int want = (int)(ye & 0xffffu) - sy0 + 1;                    // it is complete with this source row
-            const int s_first = want - 1;
-            const int s_last = (int)(yt[max(rb, 1) - 1] & 0xffffu) - sy0 + 1;
-            uint32_t hp[4] = {0u, 0u, 0u, 0u}, hc[4] = {0u, 0u, 0u, 0u};
-            for (int sr = s_first; sr <= s_last && r < rb; sr++) {
-                const uint32_t* p = reinterpret_cast<const uint32_t*>(src + sr * spitch);
-                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-                const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, shift), hi = __builtin_amdgcn_alignbyte(d2, d1, shift);
+            constexpr int kUnroll = 4;
+            for (int r = rr; r < rows; r += kUnroll * par) {
+                uint32_t ye[kUnroll], d[kUnroll][2][3];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    hp[j] = hc[j];
-                    hc[j] = dot2_u16(__builtin_amdgcn_perm(hi, lo, sel[j]), wgt[j], 0u);
+                for (int u = 0; u < kUnroll; u++) ye[u] = yt[min(r + u * par, rows - 1)];
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) {
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(src + ((ye[u] & 0xffffu) - (unsigned)sy0) * spitch);
+                    const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(p) + spitch);
+                    d[u][0][0] = p[0]; d[u][0][1] = p[1]; d[u][0][2] = p[2];
+                    d[u][1][0] = q[0]; d[u][1][1] = q[1]; d[u][1][2] = q[2];
                 }
-                // destination rows whose second source row this is (one at most while the scale is >= 1,
-                // several only among the clamped rows at the edge of the region)
-                while (r < rb && want == sr) {
-                    const unsigned m1 = ye >> 16, mw = (256u - m1) | (m1 << 16);
+#pragma unroll
+                for (int u = 0; u < kUnroll; u++) {
+                    const int ru = r + u * par;
+                    if (ru >= rows) break;
+                    uint32_t h[2][4];
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const uint32_t lo = __builtin_amdgcn_alignbyte(d[u][t][1], d[u][t][0], shift);
+                        const uint32_t hi = __builtin_amdgcn_alignbyte(d[u][t][2], d[u][t][1], shift);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) h[t][j] = dot2_u16(__builtin_amdgcn_perm(hi, lo, sel[j]), wgt[j], 0u);
+                    }
+                    const unsigned m1 = ye[u] >> 16, mw = (256u - m1) | (m1 << 16);
                     uint32_t v[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        v[j] = dot2_u16(__builtin_amdgcn_perm(hc[j], hp[j], 0x05040100u), mw, 32768u);
+                        v[j] = dot2_u16(__builtin_amdgcn_perm(h[1][j], h[0][j], 0x05040100u), mw, 32768u);
                     const uint32_t packed = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020c0cu);
-                    *reinterpret_cast<uint32_t*>(dbuf + (r * n4 + gi) * 4) = packed;
-                    const int gy = cy0 + r;
-                    if (own_x && gy >= oy0 && gy < oy1)
-                        *reinterpret_cast<uint32_t*>(gdst + (gbase + __umul24((unsigned)r, (unsigned)L.pitch))) = packed;
-                    r++;
-                    ye = yt[min(r, rows - 1)];
-                    want = (int)(ye & 0xffffu) - sy0 + 1;
+                    *reinterpret_cast<uint32_t*>(dbuf + (ru * n4 + gi) * 4) = packed;
+                    const int gy = cy0 + ru;
+                    if (SA_PYR_EXP != 2 && own_x && gy >= oy0 && gy < oy1)
+                        *reinterpret_cast<uint32_t*>(gdst + (gbase + __umul24((unsigned)ru, (unsigned)L.pitch))) = packed;
                 }
             }
         }
