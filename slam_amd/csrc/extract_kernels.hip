@@ -17,6 +17,23 @@
 #ifndef SA_DESC_EXP
 #define SA_DESC_EXP 0
 #endif
+#ifndef SA_FAST_EXP
+#define SA_FAST_EXP 0     // 1: fast_nms prints the clock at its phase boundaries for a few workgroups (timing experiments)
+#endif
+#if SA_FAST_EXP
+#define SA_STAMP_DECL unsigned long long stamp_[16] = {}
+#define SA_STAMP(i) stamp_[i] = __builtin_amdgcn_s_memtime()
+#define SA_STAMP_PRINT                                                                                              \
+    if ((threadIdx.x & 63) == 0 && b == 3 && (ftile == 75 || ftile == 200 || ftile == 300 || ftile == 420))        \
+        printf("fast tile %d lvl %d wave %d n1 %d n2 %d : %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", ftile, l, \
+               (int)(threadIdx.x >> 6), n1, n2, stamp_[1] - stamp_[0], stamp_[2] - stamp_[1],                      \
+               stamp_[3] - stamp_[2], stamp_[4] - stamp_[3], stamp_[5] - stamp_[4], stamp_[6] - stamp_[5],         \
+               stamp_[7] - stamp_[6], stamp_[8] - stamp_[7], stamp_[9] - stamp_[8], stamp_[10] - stamp_[9], stamp_[15] - stamp_[10])
+#else
+#define SA_STAMP_DECL
+#define SA_STAMP(i)
+#define SA_STAMP_PRINT
+#endif
 
 namespace sa {
 
@@ -166,6 +183,8 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         aligned = true;
     }
     const int tid = threadIdx.x;
+    SA_STAMP_DECL;
+    SA_STAMP(0);
     s_hist[tid] = 0;
     if (tid < 3) s_n[tid] = 0;
     if (tid < (kFastTileW / 8) * (kFastTileH / 8)) s_cellbest[tid] = 0;
@@ -218,7 +237,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             }
         }
     }
+    SA_STAMP(1);
     lds_barrier();
+    SA_STAMP(2);
     const int t = a.g.fast_threshold;
     const int edge = a.g.edge;
     const bool level_ok = (w > 2 * edge) && (h > 2 * edge);
@@ -297,7 +318,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             }
         }
     }
+    SA_STAMP(3);
     lds_barrier();
+    SA_STAMP(4);
     // ---- phase 2: full ring, 9 contiguous darker (or, on complemented pixels, brighter) ----
     // The sign of (ring - (v - t)) says "darker"; alignbit shifts it into the mask.
     const int n1 = (int)s_n[0];
@@ -330,7 +353,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         }
         list_append(corner, code | (pol << 12), s_list2, &s_n[1]);
     }
+    SA_STAMP(5);
     lds_barrier();
+    SA_STAMP(6);
     // ---- phase 3: score of the corners; vertical pass of the blur ----
     // The score is the largest threshold that still detects: the best arc's smallest difference,
     // minus one.  A darker corner has no brighter arc and vice versa, so one polarity suffices.
@@ -373,7 +398,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             s_v[(4 * chunk + j) * kVPitch + cp] = as_u32(s0 * k18 + s1 * k34 + s2 * k49 + s3 * k55);
         }
     }
+    SA_STAMP(7);
     lds_barrier();
+    SA_STAMP(8);
     // ---- phase 4a: NMS + border filter over the corner list ----
     // A strict 3x3 maximum has no second one among its 8 neighbours, so a 64 x 32 tile holds at
     // most 32 x 16 = kTileListCap of them: the list cannot overflow.  Its order is arbitrary
@@ -391,12 +418,11 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
                 gx >= w - edge || gy < edge || gy >= h - edge)
                 return 0u;
             const uint8_t* q = s_sc + code - 3 * P;
+            // all nine reads first: one LDS round trip instead of a chain of eight
             const int s = q[0];
-            if (s == 0) return 0u;
-            if (s > q[-1] && s > q[1] && s > q[-P - 1] && s > q[-P] && s > q[-P + 1] && s > q[P - 1] && s > q[P] &&
-                s > q[P + 1])
-                return (unsigned)lx | ((unsigned)ly << 6) | ((unsigned)s << 16);
-            return 0u;
+            const int n0 = q[-1], n1 = q[1], n2_ = q[-P - 1], n3 = q[-P], n4 = q[-P + 1], n5 = q[P - 1], n6 = q[P], n7 = q[P + 1];
+            const int top = max(max(max(n0, n1), max(n2_, n3)), max(max(n4, n5), max(n6, n7)));
+            return (s != 0 && s > top) ? ((unsigned)lx | ((unsigned)ly << 6) | ((unsigned)s << 16)) : 0u;
         };
         // Optional grid distribution (not in the reference): of the survivors of one
         // cell of grid_cell x grid_cell pixels only the best stays -- highest score,
@@ -431,6 +457,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             }
         }
     }
+    SA_STAMP(9);
     // ---- phase 4b: blur, horizontal pass: 4 pixels of one row per item, rows ly and ly + 16 ----
     // The column sums sit in 16-bit halves, {columns 4g, 4g + 2} and {4g + 1, 4g + 3} per group, so
     // every tap pair is one 16-bit dot product; min((sum + 2^15) >> 16, 255) is byte 2 of the accumulator:
@@ -458,6 +485,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             if (gy < h) *reinterpret_cast<uint32_t*>(blur + (size_t)gy * L.pitch + x0 + 4 * og) = lo | hi;
         }
     }
+    SA_STAMP(10);
     lds_barrier();   // the survivor list and the histogram are complete
     {
         const unsigned ns = min(s_n[2], (unsigned)kTileListCap);
@@ -468,6 +496,8 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     }
     const unsigned hv = s_hist[tid];
     if (hv) atomicAdd(&a.hist[((size_t)b * a.g.nlevels + l) * 256 + tid], hv);
+    SA_STAMP(15);
+    SA_STAMP_PRINT;
 }
 
 // ---------------------------------------------------------------------------
