@@ -259,12 +259,12 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         // bits 0, 1 (darker) and 2, 3 (brighter), pixels 2, 3 at bits 16 .. 19
         unsigned cmask = 0;
         if (in_grid && level_ok) {
+            // valid staged columns [clo, chi): the scored region, cut to image columns [edge - 1, w - edge]
+            const int clo = max(3, edge - 1 - (x0 - kImgHalo)), chi = min(kFastTileW + 5, w - edge + 1 - (x0 - kImgHalo));
+            const unsigned span = (unsigned)max(chi - clo, 0);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int sc = 4 * cg + j, gx = x0 - kImgHalo + sc;
-                if (sc >= 3 && sc <= kFastTileW + 4 && gx >= edge - 1 && gx < w - edge + 1)
-                    cmask |= 5u << ((j & 1) + 16 * (j >> 1));
-            }
+            for (int j = 0; j < 4; j++)
+                if ((unsigned)(4 * cg + j - clo) < span) cmask |= 5u << ((j & 1) + 16 * (j >> 1));
         }
         // held in a vector register: an add with a scalar-register operand issues at half rate
         unsigned KB = 0x02000200u - (unsigned)(t + 1) * 0x00010001u;
@@ -303,6 +303,8 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         const int incl = wave_incl_scan(cnt);
         const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total) {
+            // (one atomic per wave: per-lane atomics on the one counter serialise in the LDS and cost more
+            // than the prefix sum)
             unsigned base = 0;
             if ((tid & 63) == 0) base = atomicAdd(&s_n[0], (unsigned)total);
             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
