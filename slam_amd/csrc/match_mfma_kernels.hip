@@ -30,7 +30,13 @@
 namespace sa {
 
 constexpr int kMmBlock = 256;                 // 4 waves
-constexpr int kMmNB = 2;                      // query blocks of 32 per wave
+#ifndef SA_MM_NB
+#define SA_MM_NB 2
+#endif
+#ifndef SA_MM_KUNROLL
+#define SA_MM_KUNROLL 2
+#endif
+constexpr int kMmNB = SA_MM_NB;               // query blocks of 32 per wave
 constexpr int kMmQueries = 4 * kMmNB * 32;    // queries per workgroup
 constexpr int kMmSub = 32;                    // train rows of one product
 constexpr int kMmTile = 64;                   // train rows per LDS tile (two products)
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
         const bool more = t0 + kMmTile < t_end;
         unsigned wnext[2] = {0u, 0u};
         if (more) load_tile(t0 + kMmTile, wnext);
-#pragma unroll
+#pragma unroll SA_MM_KUNROLL
         for (int k = 0; k < 2; k++) {
             v16i acc[kMmNB];
 #pragma unroll
