@@ -801,7 +801,9 @@ static int match_common(slam_amd_matcher* m, int batch,
     bool windowed = area > 0.f && area <= 3.0e38f && nq > 0 && n2 > 0;
     if (m->window_mode == 1 || no_alloc) windowed = false;   // the full sweep needs no reordered copies
     else if (m->window_mode == 0) windowed = windowed && (long long)nq * n2 >= (1LL << 25);
-    MatchPlan plan = plan_match(batch, nq, n2, m->n_cu, second);
+    // both gates off: distances on the matrix cores (second-best keys included)
+    const bool use_mfma = !gated && m->ungated_mode == 0;
+    MatchPlan plan = use_mfma ? plan_match_mfma(batch, nq, n2, m->n_cu, second) : plan_match(batch, nq, n2, m->n_cu, second);
     if (windowed) plan.splits = window_splits(batch, nq, n2, m->n_cu);
     int rc;
     const bool capturing = !no_alloc && stream_capturing(st);
@@ -869,8 +871,7 @@ static int match_common(slam_amd_matcher* m, int batch,
         a.part = second ? part_p : nullptr;
         a.part_pitch = rows;
         ProfScope ps(kStageMatch, st);
-        if (!gated && !second && m->ungated_mode == 0) rc = launch_match_mfma(a, batch, nq, n2, m->n_cu, st);
-        else rc = launch_match(a, plan, batch, st);
+        rc = use_mfma ? launch_match_mfma(a, plan, batch, st) : launch_match(a, plan, batch, st);
         if (rc) return rc;
     }
     FinalizeArgs f;

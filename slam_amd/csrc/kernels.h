@@ -216,7 +216,8 @@ int launch_describe(const DescribeArgs& a, int batch, hipStream_t st);
 MatchPlan plan_match(int batch, int nq_bound, int nt_bound, int n_cu, bool second);
 int launch_match(MatchArgs a, const MatchPlan& p, int batch, hipStream_t st);
 int launch_match_pairs(MatchArgs a, int n_pairs, hipStream_t st);
-int launch_match_mfma(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st);
+MatchPlan plan_match_mfma(int batch, int nq_bound, int nt_bound, int n_cu, bool second);
+int launch_match_mfma(MatchArgs a, const MatchPlan& p, int batch, hipStream_t st);
 int launch_match_pairs_mfma(MatchArgs a, int n_pairs, hipStream_t st);
 int launch_spatial_sort(SpatialSortArgs a, int batch, int nq_bound, int nt_bound, hipStream_t st);
 int window_splits(int batch, int nq_bound, int nt_bound, int n_cu);

@@ -62,7 +62,9 @@ __device__ __forceinline__ v4i expand16(unsigned bits16, unsigned scale) {
     return r;
 }
 
-template <bool PAIRS>
+// SECOND: also keep the second smallest key (for the ratio test); every split then stores its
+// (best, second) pair and the finalize kernel merges the splits.
+template <bool PAIRS, bool SECOND>
 __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
     __shared__ uint4 s_tile[2][2 * kMmSubU4];
 
@@ -149,9 +151,11 @@ __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
         }
     };
 
-    int best[kMmNB];
+    int best[kMmNB], second[kMmNB];
 #pragma unroll
-    for (int b = 0; b < kMmNB; b++) best[b] = 0x7fffffff;
+    for (int b = 0; b < kMmNB; b++) best[b] = second[b] = 0x7fffffff;
+    // 32 Hrel + row  ->  Hrel << 20 | block * 32 + row: order (distance, train index)
+    auto block_key = [](int m, int blockno) { return m * (1 << kMmBlockBits) - (m & 31) * ((1 << kMmBlockBits) - 1) + blockno; };
 
     // ninth step, train side: bytes 0-3 per-dword popcounts (written per tile), byte 4 the row number,
     // bytes 5-15 zero (they meet zeros of the query side; they only have to be defined)
@@ -195,12 +199,29 @@ __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
             }
 #pragma unroll
             for (int b = 0; b < kMmNB; b++) {
-                int m = acc[b][0];
+                if (SECOND) {
+                    // the two smallest accumulators of the lane: sorted pairs, merged pairwise
+                    int lo[8], hi[8];
 #pragma unroll
-                for (int i = 1; i < 16; i += 2) m = min(min(m, acc[b][i]), acc[b][i + 1 < 16 ? i + 1 : i]);
-                // 32 Hrel + row  ->  Hrel << 20 | block * 32 + row: order (distance, train index)
-                const int row = m & 31;
-                best[b] = min(best[b], m * (1 << kMmBlockBits) - row * ((1 << kMmBlockBits) - 1) + blockno);
+                    for (int p = 0; p < 8; p++) { lo[p] = min(acc[b][2 * p], acc[b][2 * p + 1]); hi[p] = max(acc[b][2 * p], acc[b][2 * p + 1]); }
+#pragma unroll
+                    for (int w = 4; w >= 1; w >>= 1)
+#pragma unroll
+                        for (int p = 0; p < w; p++) {
+                            const int l2 = min(lo[p], lo[p + w]);
+                            hi[p] = min(max(lo[p], lo[p + w]), min(hi[p], hi[p + w]));
+                            lo[p] = l2;
+                        }
+                    const int k1 = block_key(lo[0], blockno), k2 = block_key(hi[0], blockno);
+                    // best <= second and k1 < k2: the two smallest of the four
+                    second[b] = min(max(best[b], k1), min(second[b], k2));
+                    best[b] = min(best[b], k1);
+                } else {
+                    int m = acc[b][0];
+#pragma unroll
+                    for (int i = 1; i < 16; i += 2) m = min(min(m, acc[b][i]), acc[b][i + 1 < 16 ? i + 1 : i]);
+                    best[b] = min(best[b], block_key(m, blockno));
+                }
             }
             blockno += kMmSub;
         }
@@ -211,10 +232,23 @@ __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
 
 #pragma unroll
     for (int b = 0; b < kMmNB; b++) {
-        const int m = min(best[b], __shfl_xor(best[b], 32, 64));
-        if (h != 0 || qidx[b] >= nq) continue;
+        const int ob = __shfl_xor(best[b], 32, 64);
+        const int m = min(best[b], ob);
         // m = (H - popcount(query)) << 20 | train row relative to t_begin; rows beyond the set carry distances above 256
-        const unsigned d = (unsigned)((m >> kMmIdxBits) + pq[b]);   // arithmetic shift: floor
+        auto final_key = [&](int v) -> unsigned {
+            const unsigned d = (unsigned)((v >> kMmIdxBits) + pq[b]);   // arithmetic shift: floor
+            const unsigned t = (unsigned)(t_begin + (v & ((1 << kMmIdxBits) - 1)));
+            return d <= 256u ? ((d << kMmIdxBits) | t) : kMmNoMatch;
+        };
+        if (SECOND) {
+            const int os = __shfl_xor(second[b], 32, 64);
+            const int m2 = min(max(best[b], ob), min(second[b], os));
+            if (h == 0 && qidx[b] < nq)
+                a.part[(size_t)split * a.part_pitch + qbase + qidx[b]] = make_uint2(final_key(m), final_key(m2));
+            continue;
+        }
+        if (h != 0 || qidx[b] >= nq) continue;
+        const unsigned d = (unsigned)((m >> kMmIdxBits) + pq[b]);
         const unsigned t = (unsigned)(t_begin + (m & ((1 << kMmIdxBits) - 1)));
         if (PAIRS) {
             a.pair_out[(size_t)prob * a.n_per + qidx[b]] = (d <= 256u && (int)d <= a.dmax) ? ((d << 16) | t) : kMmNoMatch;
@@ -226,19 +260,30 @@ __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
 
 // Workgroups of 256 queries; the train set is split so that the grid fills the chip several
 // times over (capacities bound the grid, the true counts live on the device; workgroups beyond
-// them exit at once).  Splits are merged by atomicMin on the key.
-int launch_match_mfma(MatchArgs a, int batch, int nq_bound, int nt_bound, int n_cu, hipStream_t st) {
-    if (nq_bound <= 0 || nt_bound <= 0 || batch <= 0) return SLAM_AMD_OK;
-    const int qblocks = div_up(nq_bound, kMmQueries);
-    int splits = div_up(n_cu * 6, qblocks * batch);
+// them exit at once).  Splits are merged by atomicMin on the key -- or, when second-best keys are
+// kept, in the finalize kernel over at most kMaxSecondSplits planes.
+MatchPlan plan_match_mfma(int batch, int nq_bound, int nt_bound, int n_cu, bool second) {
+    MatchPlan p = {0, 0, 1, 0};
+    if (nq_bound <= 0 || nt_bound <= 0 || batch <= 0) return p;
+    p.qblocks = div_up(nq_bound, kMmQueries);
+    int splits = div_up(n_cu * 6, p.qblocks * batch);
     splits = std::max(1, std::min(splits, div_up(nt_bound, 4 * kMmTile)));
-    a.chunk = div_up(div_up(nt_bound, splits), kMmTile) * kMmTile;
-    a.splits = div_up(nt_bound, a.chunk);
-    a.qblocks = qblocks;
+    if (second) splits = std::min(splits, kMaxSecondSplits);
+    p.chunk = div_up(div_up(nt_bound, splits), kMmTile) * kMmTile;
+    p.splits = div_up(nt_bound, p.chunk);
+    return p;
+}
+
+int launch_match_mfma(MatchArgs a, const MatchPlan& p, int batch, hipStream_t st) {
+    if (p.qblocks <= 0 || batch <= 0) return SLAM_AMD_OK;
+    a.chunk = p.chunk;
+    a.splits = p.splits;
+    a.qblocks = p.qblocks;
     a.batch = batch;
-    const long long blocks = (long long)qblocks * a.splits * batch;
+    const long long blocks = (long long)p.qblocks * p.splits * batch;
     if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match: problem too large for one launch");
-    hipLaunchKernelGGL(match_mfma_kernel<false>, dim3((unsigned)blocks), dim3(kMmBlock), 0, st, a);
+    if (a.part) hipLaunchKernelGGL((match_mfma_kernel<false, true>), dim3((unsigned)blocks), dim3(kMmBlock), 0, st, a);
+    else hipLaunchKernelGGL((match_mfma_kernel<false, false>), dim3((unsigned)blocks), dim3(kMmBlock), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }
@@ -250,7 +295,7 @@ int launch_match_pairs_mfma(MatchArgs a, int n_pairs, hipStream_t st) {
     a.splits = 1;
     const long long blocks = (long long)a.qblocks * n_pairs;
     if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match_pairs: too many pairs for one launch");
-    hipLaunchKernelGGL(match_mfma_kernel<true>, dim3((unsigned)blocks), dim3(kMmBlock), 0, st, a);
+    hipLaunchKernelGGL((match_mfma_kernel<true, false>), dim3((unsigned)blocks), dim3(kMmBlock), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }
