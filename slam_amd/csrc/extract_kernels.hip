@@ -1067,15 +1067,29 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
     // it keeps a record that was never written (zeros) or a count that ran ahead of the records from
     // becoming a wild read.  (24 = patch radius 18 + the up to 3 + 3 bytes the aligned dword loads
     // reach further.)
+    // The positions of the workgroup's keypoints and the geometry of every level are fetched once,
+    // one per lane, and handed out by v_readlane: no memory operation (and no wait for the patch
+    // loads in flight) stands between two keypoints.
+    uint32_t xyv = 0xffffffffu;                       // level 15: rejected
+    if (lane < kDescKps && i0 + lane < n) xyv = kpxy[i0 + lane];
+    int gw = 0, gh = 0, gpitch = 0;
+    unsigned goff = 0;
+    float gscale = 0.f;
+    if (lane < a.g.nlevels) {
+        const LevelGeom& Lg = a.g.lv[lane];
+        gw = Lg.w; gh = Lg.h; gpitch = Lg.pitch; goff = Lg.off; gscale = Lg.scale;
+    }
     auto locate = [&](int i, int& x, int& y, int& l) -> bool {
-        const uint32_t xy = kpxy[i];
+        const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)xyv, i - i0);
         x = (int)(xy & 0x3fffu);
         y = (int)((xy >> 14) & 0x3fffu);
         l = (int)(xy >> 28);
         if (l >= a.g.nlevels) return false;
-        const LevelGeom& L = a.g.lv[l];
-        return !(x < 24 || y < 24 || x >= L.w - 24 || y >= L.h - 24);
+        const int lw = __builtin_amdgcn_readlane(gw, l), lh = __builtin_amdgcn_readlane(gh, l);
+        return !(x < 24 || y < 24 || x >= lw - 24 || y >= lh - 24);
     };
+    auto level_pitch = [&](int l) { return __builtin_amdgcn_readlane(gpitch, l); };
+    auto level_off = [&](int l) { return (unsigned)__builtin_amdgcn_readlane((int)goff, l); };
 
     // ---- pass 1: intensity centroid of every keypoint (one wave per keypoint, 16 in a row) ----
     // Lanes 0-30 own the columns u = -15..15 for the rows v = -15..0, lanes 32-62 the
@@ -1096,8 +1110,8 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
                 pitch = a.img0_pitch;
                 aligned = a.img0_aligned != 0;
             } else {
-                img = pyr + a.g.lv[l].off;
-                pitch = a.g.lv[l].pitch;
+                img = pyr + level_off(l);
+                pitch = level_pitch(l);
             }
         };
         PatchRegs<kURad, kUPitch> cur;
@@ -1188,7 +1202,7 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
         bool ok = false;
         const int first = i0 + wave * kDescPerWave;
         if (first < n && (ok = locate(first, x, y, l)))
-            patch_load(cur, blurf + a.g.lv[l].off, a.g.lv[l].pitch, x, y, lane);
+            patch_load(cur, blurf + level_off(l), level_pitch(l), x, y, lane);
 #pragma unroll 1
         for (int j = 0; j < kDescPerWave; j++) {
             const int slot = wave * kDescPerWave + j, i = i0 + slot;
@@ -1199,9 +1213,9 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
             int xn = 0, yn = 0, ln = 0;
             bool okn = false;
             if (j + 1 < kDescPerWave && i + 1 < n && (okn = locate(i + 1, xn, yn, ln)))
-                patch_load(nxt, blurf + a.g.lv[ln].off, a.g.lv[ln].pitch, xn, yn, lane);
+                patch_load(nxt, blurf + level_off(ln), level_pitch(ln), xn, yn, lane);
             if (ok) {
-                const LevelGeom& L = a.g.lv[l];
+                const float lscale = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gscale), l));
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1226,8 +1240,8 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
                     out[0] = make_uint4((unsigned)bits[0], (unsigned)(bits[0] >> 32), (unsigned)bits[1], (unsigned)(bits[1] >> 32));
                     out[1] = make_uint4((unsigned)bits[2], (unsigned)(bits[2] >> 32), (unsigned)bits[3], (unsigned)(bits[3] >> 32));
                     slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity + i;
-                    kp->x = SA_FMUL((float)x, L.scale);
-                    kp->y = SA_FMUL((float)y, L.scale);
+                    kp->x = SA_FMUL((float)x, lscale);
+                    kp->y = SA_FMUL((float)y, lscale);
                 }
             }
             cur = nxt; x = xn; y = yn; l = ln; ok = okn;
