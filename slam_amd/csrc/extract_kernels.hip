@@ -7,8 +7,8 @@
 //   select_compact                per-level cut score from the histogram (retain-best), then
 //                                 the kept survivors of every row's sparse list -> keypoints
 //                                 in canonical (octave, y, x) order
-//   describe                      intensity-centroid angle + 7x7 blur + rBRIEF,
-//                                 one wavefront per keypoint, patch held in LDS
+//   describe                      intensity-centroid angle + rBRIEF on the blurred level,
+//                                 one wavefront on one keypoint at a time, patch held in LDS
 #include "common.h"
 #include "detmath.h"
 #include "kernels.h"
@@ -921,20 +921,30 @@ __global__ __launch_bounds__(1024) void quadtree_select_kernel(SelectCompactArgs
 }
 
 // ---------------------------------------------------------------------------
-// Describe: a single-wave workgroup takes 8 consecutive keypoints of one frame, one at a
-// time (everything derived from the keypoint index is scalar): first the intensity
-// centroids of all 8, then -- one keypoint per lane, so that the per-keypoint scalar
-// arithmetic (atan2, the double-precision cos / sin) is done once for the 8 instead of 8
-// times on all lanes -- the angles, then the descriptors.  No workgroup barrier is needed.
-// Two patches are staged in LDS with aligned 4-byte loads:
-// 31 x 31 of the unblurred level (intensity centroid over the radius-15 disc) and
-// 37 x 37 of the blurred level (256 rotated rBRIEF comparisons, 4 per lane, assembled
-// by ballot; the rotated pattern reaches at most 18 pixels).  Keypoints lie >= 31
-// pixels from the level border, so both patches are inside the level.
+// Describe: a single-wave workgroup takes kDescKps consecutive keypoints of one frame.
+// Everything that belongs to one keypoint (position, level, patch addresses, later its
+// moments, angle, cos / sin and the finished descriptor) lives in the registers of one
+// lane, keypoint j in lane j; what the whole wave needs of it is handed out by
+// v_readlane, and results go back by v_writelane.  The scalar unit then has next to
+// nothing to do per keypoint, which matters: scalar instructions are not free on this
+// chip (a wave that issues one per two vector instructions already runs a quarter
+// slower than the vector instructions alone).
+//   pass 1  intensity centroid of every keypoint, the wave on one keypoint at a time
+//   pass 2  angle, cos / sin, keypoint record: one keypoint per lane, once
+//   pass 3  256 rotated rBRIEF comparisons per keypoint, 4 per lane, assembled by ballot
+// A patch is staged in LDS by two 16-byte loads per lane -- rows of 48 bytes starting at
+// the 4-byte boundary at or before the patch's first column, (row, chunk) = (lane / 3,
+// lane % 3) and 21 rows further down, clamped to the last row -- 31 rows of the unblurred
+// level for pass 1 (radius-15 disc) and 37 of the blurred level for pass 3 (the rotated
+// pattern reaches at most 18 pixels).  The loads of the next keypoint are in flight
+// while the current one is processed.  Keypoints lie >= 31 pixels from the level border,
+// so both patches are inside the level, and the bytes a row's 48 reach beyond the patch
+// are inside the level buffer (never used).  No workgroup barrier is needed.
 // ---------------------------------------------------------------------------
-constexpr int kURad = 15, kURows = 31, kUPitch = 36;   // 31 columns + up to 3 alignment bytes
-constexpr int kBRad = 18, kBRows = 37, kBPitch = 40;   // 37 columns + up to 3 alignment bytes
-constexpr int kWaveLds = kURows * kUPitch + kBRows * kBPitch;  // 2596
+constexpr int kURad = 15, kURows = 31;
+constexpr int kBRad = 18, kBRows = 37;
+constexpr int kPPitch = 48;        // LDS bytes per patch row
+constexpr int kPRows0 = 21;        // rows covered by the first load of a patch (63 lanes)
 
 // rBRIEF sampling pattern as floats: x0, y0, x1, y1 of pair p at [4 * p].
 __constant__ __align__(16) float c_pattern[256 * 4] = {
@@ -949,303 +959,224 @@ __device__ __forceinline__ int disc_half_width(int av) {
     return (int)((packed >> (4 * av)) & 15u);
 }
 
-// Copies rows [y - R, y + R] x columns [x - R, x + R] of img into LDS.  Returns
-// the column shift: patch column c of row r is at dst[r * PITCH + shift + c].
-// A lane keeps one (row, dword) position of a block of 64 / DW rows and walks
-// down the patch block by block: the loads of all blocks are issued together.
-template <int R, int PITCH>
-__device__ __forceinline__ int stage_patch(const uint8_t* img, int pitch, bool aligned, int x, int y,
-                                           uint8_t* dst, int lane) {
-    constexpr int ROWS = 2 * R + 1;
-    const uint8_t* p0 = img + (size_t)(y - R) * pitch + (x - R);
-    if (aligned) {
-        constexpr int DW = PITCH / 4, RPI = 64 / DW, ITERS = (ROWS + RPI - 1) / RPI;
-        const int shift = (int)(reinterpret_cast<uintptr_t>(p0) & 3);
-        const uint8_t* base = p0 - shift;
-        const int lr = lane / DW, lc = lane - lr * DW;
-        const unsigned voff = (unsigned)(lr * pitch + 4 * lc);
-        uint8_t* d = dst + lr * PITCH + 4 * lc;
-        uint32_t v[ITERS];
-#pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-            v[it] = 0;
-            if (lr < RPI && lr + it * RPI < ROWS)
-                v[it] = *reinterpret_cast<const uint32_t*>(base + (size_t)(it * RPI) * pitch + voff);
-        }
-#pragma unroll
-        for (int it = 0; it < ITERS; it++)
-            if (lr < RPI && lr + it * RPI < ROWS)
-                *reinterpret_cast<uint32_t*>(d + it * RPI * PITCH) = v[it];
-        return shift;
-    }
-    for (int k = lane; k < ROWS * ROWS; k += 64) {
-        const int r = k / ROWS, c = k - r * ROWS;
-        dst[r * PITCH + c] = p0[(size_t)r * pitch + c];
-    }
-    return 0;
-}
-
-// The same copy in two steps, so that the loads of the next keypoint's patch are in flight while the
-// current one is processed: patch_load issues the aligned dword loads into registers (the image rows
-// must be 4-byte aligned), patch_store writes them to LDS and returns the column shift.
-template <int R, int PITCH>
-struct PatchRegs {
-    static constexpr int ROWS = 2 * R + 1, DW = PITCH / 4, RPI = 64 / DW, ITERS = (ROWS + RPI - 1) / RPI;
-    uint32_t v[ITERS];
-    int shift;
-};
-
-template <int R, int PITCH>
-__device__ __forceinline__ void patch_load(PatchRegs<R, PITCH>& pr, const uint8_t* img, int pitch, int x, int y, int lane) {
-    typedef PatchRegs<R, PITCH> PR;
-    const uint8_t* p0 = img + (size_t)(y - R) * pitch + (x - R);
-    pr.shift = (int)(reinterpret_cast<uintptr_t>(p0) & 3);
-    const uint8_t* base = p0 - pr.shift;
-    const int lr = lane / PR::DW, lc = lane - lr * PR::DW;
-    const unsigned voff = (unsigned)(lr * pitch + 4 * lc);
-#pragma unroll
-    for (int it = 0; it < PR::ITERS; it++) {
-        pr.v[it] = 0;
-#if SA_DESC_EXP == 1
-        if (lr < PR::RPI && lr + it * PR::RPI < PR::ROWS && pitch < 0)
-#else
-        if (lr < PR::RPI && lr + it * PR::RPI < PR::ROWS)
-#endif
-            pr.v[it] = *reinterpret_cast<const uint32_t*>(base + (size_t)(it * PR::RPI) * pitch + voff);
-    }
-}
-
-template <int R, int PITCH>
-__device__ __forceinline__ int patch_store(const PatchRegs<R, PITCH>& pr, uint8_t* dst, int lane) {
-    typedef PatchRegs<R, PITCH> PR;
-    const int lr = lane / PR::DW, lc = lane - lr * PR::DW;
-    uint8_t* d = dst + lr * PITCH + 4 * lc;
-#pragma unroll
-    for (int it = 0; it < PR::ITERS; it++)
-        if (lr < PR::RPI && lr + it * PR::RPI < PR::ROWS)
-            *reinterpret_cast<uint32_t*>(d + it * PR::RPI * PITCH) = pr.v[it];
-    return pr.shift;
-}
-
-// Sum over the 64 lanes, returned in a scalar register: butterfly inside each row of
-// 16 lanes with DPP, then the four row sums are read out.
-__device__ __forceinline__ int wave_sum_i32(int v) {
+// Sum over the 64 lanes, left in lane 63: butterfly inside each row of 16 lanes, then the row
+// totals are passed up (rows 1 and 3 take the row before, rows 2 and 3 the half before).
+__device__ __forceinline__ int wave_sum_to_lane63(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
     v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
     v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror
     v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);  // row_mirror
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
-           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return v;
 }
+
+// v_writelane: lane `lane` of every v takes the (wave-uniform) value next to it.  The lane select travels
+// in M0 (an instruction reads at most one scalar register besides it), which nothing else in these
+// kernels uses; it is set in the statement that reads it.
+__device__ __forceinline__ void write_lane2(int& v0, int& v1, int a0, int a1, int lane) {
+    asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                 : "+v"(v0), "+v"(v1) : "s"(a0), "s"(a1), "s"(lane));
+}
+__device__ __forceinline__ void write_lane8(unsigned (&v)[8], const unsigned long long (&a)[4], int lane) {
+    asm volatile("s_mov_b32 m0, %12\n\ts_nop 0\n\t"
+                 "v_writelane_b32 %0, %8, m0\n\tv_writelane_b32 %1, %9, m0\n\t"
+                 "v_writelane_b32 %2, %10, m0\n\tv_writelane_b32 %3, %11, m0\n\t"
+                 "v_writelane_b32 %4, %13, m0\n\tv_writelane_b32 %5, %14, m0\n\t"
+                 "v_writelane_b32 %6, %15, m0\n\tv_writelane_b32 %7, %16, m0"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 : "s"((unsigned)a[0]), "s"((unsigned)(a[0] >> 32)), "s"((unsigned)a[1]), "s"((unsigned)(a[1] >> 32)), "s"(lane),
+                   "s"((unsigned)a[2]), "s"((unsigned)(a[2] >> 32)), "s"((unsigned)a[3]), "s"((unsigned)(a[3] >> 32)));
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(4))) u32x4_a4;   // a 16-byte load from a 4-byte aligned address
+struct PatchRegs { u32x4 v0, v1; };
 
 #ifndef SA_DESC_KPS
 #define SA_DESC_KPS 8
 #endif
 constexpr int kDescKps = SA_DESC_KPS;                   // keypoints per (single-wave) workgroup
-constexpr int kDescPerWave = kDescKps;         // handled one after the other
 
+// AL0: the rows of the caller's image (level 0) are 4-byte aligned.  Otherwise the unblurred
+// patch of a level-0 keypoint is staged byte by byte.
+template <bool AL0>
 __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
-    __shared__ __align__(16) uint8_t s_all[1][kWaveLds + 64];
-    __shared__ int s_m[kDescKps][2];       // m10, m01 of every keypoint of the workgroup
-    __shared__ float s_rot[kDescKps][2];   // cos, sin of its angle
+    __shared__ __align__(16) uint8_t s_patch[kBRows * kPPitch];
     // 1-D grid, frame index fastest, so the workgroups beyond the last keypoint of
     // every frame (they exit at once) sit at the end of the grid.
     const int b = blockIdx.x % a.batch;
     const int i0 = (blockIdx.x / a.batch) * kDescKps;
     const int n = min(a.sel[b].total, a.capacity);
     if (i0 >= n) return;
+    const int nk = min(kDescKps, n - i0);
     const int lane = threadIdx.x;
-    constexpr int wave = 0;
-    uint8_t* s_u = s_all[wave];
-    uint8_t* s_b = s_all[wave] + kURows * kUPitch;
-    const uint8_t* pyr = a.pyr + (size_t)b * a.g.frame_bytes;
-    const uint8_t* blurf = a.blur + (size_t)b * a.g.frame_bytes;
-    const uint32_t* kpxy = a.kpxy + (size_t)b * a.capacity;
+    auto exchange = [](int from_lane, int v) { return __builtin_amdgcn_ds_bpermute(4 * from_lane, v); };
 
-    // Position of keypoint i; false if its patches would leave the level.  The selection kernel only
-    // emits positions at least `edge` (>= 31) pixels from the border, so this rejects nothing it wrote;
-    // it keeps a record that was never written (zeros) or a count that ran ahead of the records from
-    // becoming a wild read.  (24 = patch radius 18 + the up to 3 + 3 bytes the aligned dword loads
-    // reach further.)
-    // The positions of the workgroup's keypoints and the geometry of every level are fetched once,
-    // one per lane, and handed out by v_readlane: no memory operation (and no wait for the patch
-    // loads in flight) stands between two keypoints.
-    uint32_t xyv = 0xffffffffu;                       // level 15: rejected
-    if (lane < kDescKps && i0 + lane < n) xyv = kpxy[i0 + lane];
-    int gw = 0, gh = 0, gpitch = 0;
-    unsigned goff = 0;
-    float gscale = 0.f;
+    // ---- per lane, once: geometry of level `lane`, then everything about keypoint `lane` ----
+    int gw = 0, gh = 0, gpitch = 0, goff = 0, gscale = 0;
     if (lane < a.g.nlevels) {
         const LevelGeom& Lg = a.g.lv[lane];
-        gw = Lg.w; gh = Lg.h; gpitch = Lg.pitch; goff = Lg.off; gscale = Lg.scale;
+        gw = Lg.w; gh = Lg.h; gpitch = Lg.pitch; goff = (int)Lg.off; gscale = __builtin_bit_cast(int, Lg.scale);
     }
-    auto locate = [&](int i, int& x, int& y, int& l) -> bool {
-        const uint32_t xy = (uint32_t)__builtin_amdgcn_readlane((int)xyv, i - i0);
-        x = (int)(xy & 0x3fffu);
-        y = (int)((xy >> 14) & 0x3fffu);
-        l = (int)(xy >> 28);
-        if (l >= a.g.nlevels) return false;
-        const int lw = __builtin_amdgcn_readlane(gw, l), lh = __builtin_amdgcn_readlane(gh, l);
-        return !(x < 24 || y < 24 || x >= lw - 24 || y >= lh - 24);
-    };
-    auto level_pitch = [&](int l) { return __builtin_amdgcn_readlane(gpitch, l); };
-    auto level_off = [&](int l) { return (unsigned)__builtin_amdgcn_readlane((int)goff, l); };
+    uint32_t xyv = 0xffffffffu;                       // level 15: rejected
+    if (lane < nk) xyv = a.kpxy[(size_t)b * a.capacity + i0 + lane];
+    const int px = (int)(xyv & 0x3fffu), py = (int)((xyv >> 14) & 0x3fffu), pl = (int)(xyv >> 28);
+    const bool lvl_ok = pl < a.g.nlevels;
+    const int lsel = lvl_ok ? pl : 0;
+    const int lw = exchange(lsel, gw), lh = exchange(lsel, gh), lpitch = exchange(lsel, gpitch);
+    const unsigned loff = (unsigned)exchange(lsel, goff);
+    const float lscale = __builtin_bit_cast(float, exchange(lsel, gscale));
+    // The selection kernel only emits positions at least `edge` (>= 31) pixels from the border, so this
+    // rejects nothing it wrote; it keeps a record that was never written (zeros) or a count that ran ahead
+    // of the records from becoming a wild read.  (24 = patch radius 18 + the up to 3 bytes of alignment;
+    // a row's 48 bytes may run past the level's right border into the next row, which exists.)
+    const bool okv = lvl_ok && !(px < 24 || py < 24 || px >= lw - 24 || py >= lh - 24);
+    const bool slowv = !AL0 && okv && pl == 0;
+    const unsigned slowbits = AL0 ? 0u : (unsigned)__ballot(slowv);
+    // First byte of the patches, moved back to a 4-byte boundary; the distance and the row pitch, packed.
+    // A lane without a valid keypoint points at the start of the frame's buffers with a row pitch of 0:
+    // the passes below run for it like for any other and its results are dropped at the end.
+    const uint8_t* ulevel = pl == 0 ? a.img0 + (size_t)b * a.img0_frame_pitch : a.pyr + (size_t)b * a.g.frame_bytes + loff;
+    const int upitch = pl == 0 ? a.img0_pitch : lpitch;
+    const uint8_t* up0 = ulevel + (ptrdiff_t)(py - kURad) * upitch + (px - kURad);
+    const unsigned su = slowv ? 0u : (unsigned)(reinterpret_cast<uintptr_t>(up0) & 3);
+    const uint8_t* bp0 = a.blur + (size_t)b * a.g.frame_bytes + loff + (ptrdiff_t)(py - kBRad) * lpitch + (px - kBRad);
+    const unsigned sb = (unsigned)(reinterpret_cast<uintptr_t>(bp0) & 3);
+    const unsigned long long uaddr = okv ? reinterpret_cast<uintptr_t>(up0) - su : reinterpret_cast<uintptr_t>(a.pyr + (size_t)b * a.g.frame_bytes);
+    const unsigned long long baddr = okv ? reinterpret_cast<uintptr_t>(bp0) - sb : reinterpret_cast<uintptr_t>(a.blur + (size_t)b * a.g.frame_bytes);
+    const int upk = okv ? (upitch << 2) | (int)su : 0;
+    const int bpk = okv ? (lpitch << 2) | (int)sb : 0;
+    const int ualo = (int)(unsigned)uaddr, uahi = (int)(unsigned)(uaddr >> 32);
+    const int balo = (int)(unsigned)baddr, bahi = (int)(unsigned)(baddr >> 32);
 
-    // ---- pass 1: intensity centroid of every keypoint (one wave per keypoint, 16 in a row) ----
+    // ---- per lane, once: its place in a patch ----
+    const int lr = lane / 3, lc = lane - 3 * lr;          // lane 63: row 21, which the second load covers too
+    const int lr1u = min(kPRows0 + lr, kURows - 1), lr1b = min(kPRows0 + lr, kBRows - 1);
+    uint8_t* const w0 = s_patch + lr * kPPitch + 16 * lc;
+    uint8_t* const w1u = s_patch + lr1u * kPPitch + 16 * lc;
+    uint8_t* const w1b = s_patch + lr1b * kPPitch + 16 * lc;
+    typedef const __attribute__((address_space(1))) uint8_t* global_bytes_t;
+    typedef const __attribute__((address_space(1))) u32x4_a4* global_u4_t;
+    auto patch_base = [&](int alo, int ahi, int j) {
+        return (global_bytes_t)((unsigned long long)(unsigned)__builtin_amdgcn_readlane(alo, j) |
+                                ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ahi, j) << 32));
+    };
+    auto patch_load = [&](PatchRegs& r, int alo, int ahi, int pk, int j, int lr1) {
+        global_bytes_t base = patch_base(alo, ahi, j);
+        const int pitch = __builtin_amdgcn_readlane(pk, j) >> 2;
+        r.v0 = *(global_u4_t)(base + (__umul24((unsigned)lr, (unsigned)pitch) + 16u * (unsigned)lc));
+        r.v1 = *(global_u4_t)(base + (__umul24((unsigned)lr1, (unsigned)pitch) + 16u * (unsigned)lc));
+    };
+    auto patch_store = [&](const PatchRegs& r, uint8_t* w1) {
+        *reinterpret_cast<u32x4*>(w0) = r.v0;
+        *reinterpret_cast<u32x4*>(w1) = r.v1;
+    };
+    // LDS traffic of one wave executes in order; this only keeps the compiler from moving LDS
+    // reads and writes across it.
+    auto lds_order = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    // ---- pass 1: intensity centroid, one keypoint at a time ----
     // Lanes 0-30 own the columns u = -15..15 for the rows v = -15..0, lanes 32-62 the
     // same columns for v = 1..15.  A lane adds up its column (rows outside the disc
     // masked off) and the row-weighted sum; the column weight is applied once.
-    const int col = lane & 31, half = lane >> 5;
-    const int u = col - 15;
-    const int vlim = col < 31 ? disc_half_width(u < 0 ? -u : u) : -1;  // |v| <= vlim is inside
-    const int vbase = half ? 1 : -15;                                  // v = vbase + vv, vv = 0..15
-    const int lo = half ? 0 : 15 - vlim, hi = half ? vlim - 1 : 15;    // vv range inside the disc
-    const unsigned rows = hi >= lo ? (2u << hi) - (1u << lo) : 0u;
+    int m10v = 0, m01v = 0;     // moments of keypoint `lane`
     {
-        // level image of keypoint level l
-        auto level_image = [&](int l, const uint8_t*& img, int& pitch, bool& aligned) {
-            aligned = true;
-            if (l == 0) {
-                img = a.img0 + (size_t)b * a.img0_frame_pitch;
-                pitch = a.img0_pitch;
-                aligned = a.img0_aligned != 0;
+        const int col = lane & 31, half = lane >> 5;
+        const int u = col - 15;
+        const int vlim = col < 31 ? disc_half_width(u < 0 ? -u : u) : -1;  // |v| <= vlim is inside
+        const int vbase = half ? 1 : -15;                                  // v = vbase + vv, vv = 0..15
+        const int lo = half ? 0 : 15 - vlim, hi = half ? vlim - 1 : 15;    // vv range inside the disc
+        const unsigned rows = hi >= lo ? (2u << hi) - (1u << lo) : 0u;
+        // column 31 (u = 16) and row v = 16 are masked off; their reads stay inside s_patch
+        const uint8_t* col0 = s_patch + (kURad + vbase) * kPPitch + kURad + u;
+        PatchRegs cur;
+        patch_load(cur, ualo, uahi, upk, 0, lr1u);
+#pragma unroll 1
+        for (int j = 0; j < nk; j++) {
+            if (!AL0 && ((slowbits >> j) & 1u)) {
+                global_bytes_t p0 = patch_base(ualo, uahi, j);
+                const int pitch = __builtin_amdgcn_readlane(upk, j) >> 2;
+                for (int k = lane; k < kURows * kURows; k += 64) {
+                    const int r = k / kURows, c = k - r * kURows;
+                    s_patch[r * kPPitch + c] = p0[(size_t)r * pitch + c];
+                }
             } else {
-                img = pyr + level_off(l);
-                pitch = level_pitch(l);
+                patch_store(cur, w1u);
             }
-        };
-        PatchRegs<kURad, kUPitch> cur;
-        int x = 0, y = 0, l = 0;
-        bool ok = false, al = true;
-        const int first = i0 + wave * kDescPerWave;
-        if (first < n && (ok = locate(first, x, y, l))) {
-            const uint8_t* img; int pitch;
-            level_image(l, img, pitch, al);
-            if (al) patch_load(cur, img, pitch, x, y, lane);
-        }
-#pragma unroll 1
-        for (int j = 0; j < kDescPerWave; j++) {
-            const int slot = wave * kDescPerWave + j, i = i0 + slot;
-            if (i >= n) break;
-            int su = 0;
-            if (ok) {
-                if (al) {
-                    su = patch_store(cur, s_u, lane);
-                } else {
-                    const uint8_t* img; int pitch; bool dummy;
-                    level_image(l, img, pitch, dummy);
-                    su = stage_patch<kURad, kUPitch>(img, pitch, false, x, y, s_u, lane);
-                }
-            }
-            // the next keypoint's loads go out before this one's arithmetic
-            PatchRegs<kURad, kUPitch> nxt;
-            int xn = 0, yn = 0, ln = 0;
-            bool okn = false, aln = true;
-            if (j + 1 < kDescPerWave && i + 1 < n && (okn = locate(i + 1, xn, yn, ln))) {
-                const uint8_t* img; int pitch;
-                level_image(ln, img, pitch, aln);
-                if (aln) patch_load(nxt, img, pitch, xn, yn, lane);
-            }
-            int m10 = 0, m01 = 0;
-            if (ok) {
-                // LDS traffic of one wave executes in order; this only keeps the compiler from
-                // moving the reads above the writes.
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // column 31 (u = 16) and row v = 16 are masked off; their reads stay inside s_all
-                const uint8_t* colp = s_u + (kURad + vbase) * kUPitch + su + kURad + u;
-                int colsum = 0, vsum = 0;
+            // the next keypoint's loads go out before this one's arithmetic (the last one is fetched twice)
+            patch_load(cur, ualo, uahi, upk, min(j + 1, nk - 1), lr1u);
+            lds_order();
+            const uint8_t* colp = col0 + (__builtin_amdgcn_readlane(upk, j) & 3);
+            int colsum = 0, vsum = 0;
 #pragma unroll
-                for (int vv = 0; vv < 16; vv++) {
-                    int val = colp[vv * kUPitch];
-                    val &= ((int)(rows << (31 - vv))) >> 31;
-                    colsum += val;
-                    vsum += vv * val;
-                }
-                m10 = wave_sum_i32(u * colsum);
-                m01 = wave_sum_i32(vbase * colsum + vsum);
-                // the next keypoint's patch overwrites s_u: reads first
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int vv = 0; vv < 16; vv++) {
+                int val = colp[vv * kPPitch];
+                val &= ((int)(rows << (31 - vv))) >> 31;
+                colsum += val;
+                vsum += vv * val;
             }
-            if (lane == 0) { s_m[slot][0] = m10; s_m[slot][1] = m01; }
-            cur = nxt; x = xn; y = yn; l = ln; ok = okn; al = aln;
+            const int m10 = __builtin_amdgcn_readlane(wave_sum_to_lane63(u * colsum), 63);
+            const int m01 = __builtin_amdgcn_readlane(wave_sum_to_lane63(vbase * colsum + vsum), 63);
+            write_lane2(m10v, m01v, m10, m01, j);
+            lds_order();   // the next keypoint's patch overwrites s_patch: reads first
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- pass 2: angle, cos and sin of all keypoints of the workgroup at once, one per lane ----
-    int px, py, pl;
-    if (threadIdx.x < kDescKps && i0 + (int)threadIdx.x < n && locate(i0 + (int)threadIdx.x, px, py, pl)) {
-        const int slot = threadIdx.x;
-        const float angle = fast_atan2_deg((float)s_m[slot][1], (float)s_m[slot][0]);
+    // ---- pass 2: angle, cos and sin, keypoint record: every keypoint in its own lane ----
+    float cav = 0.f, snv = 0.f;
+    if (okv) {
+        const float angle = fast_atan2_deg((float)m01v, (float)m10v);
         const float rad = SA_FMUL(angle, (float)(3.14159265358979323846 / 180.0));
-        float ca, sn;
-        sincos_f32(rad, &ca, &sn);
-        s_rot[slot][0] = ca;
-        s_rot[slot][1] = sn;
-        a.kp[(size_t)b * a.capacity + i0 + slot].angle = angle;
+        sincos_f32(rad, &cav, &snv);
+        slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity + i0 + lane;
+        kp->x = SA_FMUL((float)px, lscale);
+        kp->y = SA_FMUL((float)py, lscale);
+        kp->angle = angle;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- pass 3: rBRIEF, pair p = 64*k + lane, k = 0..3; ballot k holds bytes 8k..8k+7 ----
-    float4 pat[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const float4*>(c_pattern)[64 * k + lane];
+    unsigned dsc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // descriptor of keypoint `lane`
     {
-        PatchRegs<kBRad, kBPitch> cur;
-        int x = 0, y = 0, l = 0;
-        bool ok = false;
-        const int first = i0 + wave * kDescPerWave;
-        if (first < n && (ok = locate(first, x, y, l)))
-            patch_load(cur, blurf + level_off(l), level_pitch(l), x, y, lane);
-#pragma unroll 1
-        for (int j = 0; j < kDescPerWave; j++) {
-            const int slot = wave * kDescPerWave + j, i = i0 + slot;
-            if (i >= n) break;
-            int sb = 0;
-            if (ok) sb = patch_store(cur, s_b, lane);
-            PatchRegs<kBRad, kBPitch> nxt;
-            int xn = 0, yn = 0, ln = 0;
-            bool okn = false;
-            if (j + 1 < kDescPerWave && i + 1 < n && (okn = locate(i + 1, xn, yn, ln)))
-                patch_load(nxt, blurf + level_off(ln), level_pitch(ln), xn, yn, lane);
-            if (ok) {
-                const float lscale = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gscale), l));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const float ca = s_rot[slot][0], sb_ = s_rot[slot][1];
-                const uint8_t* bc = s_b + kBRad * kBPitch + sb + kBRad;
-                unsigned long long bits[4];
+        float4 pat[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int ix0 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].x, ca), SA_FMUL(pat[k].y, sb_)));
-                    const int iy0 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].x, sb_), SA_FMUL(pat[k].y, ca)));
-                    const int ix1 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].z, ca), SA_FMUL(pat[k].w, sb_)));
-                    const int iy1 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].z, sb_), SA_FMUL(pat[k].w, ca)));
-                    const int t0 = bc[iy0 * kBPitch + ix0];
-                    const int t1 = bc[iy1 * kBPitch + ix1];
-                    bits[k] = __ballot(t0 < t1);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (lane == 0) {
-                    uint4* out = reinterpret_cast<uint4*>(a.desc + ((size_t)b * a.capacity + i) * 32);
-                    out[0] = make_uint4((unsigned)bits[0], (unsigned)(bits[0] >> 32), (unsigned)bits[1], (unsigned)(bits[1] >> 32));
-                    out[1] = make_uint4((unsigned)bits[2], (unsigned)(bits[2] >> 32), (unsigned)bits[3], (unsigned)(bits[3] >> 32));
-                    slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity + i;
-                    kp->x = SA_FMUL((float)x, lscale);
-                    kp->y = SA_FMUL((float)y, lscale);
-                }
+        for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const float4*>(c_pattern)[64 * k + lane];
+        const uint8_t* centre = s_patch + kBRad * kPPitch + kBRad;
+        PatchRegs cur;
+        patch_load(cur, balo, bahi, bpk, 0, lr1b);
+#pragma unroll 1
+        for (int j = 0; j < nk; j++) {
+            patch_store(cur, w1b);
+            patch_load(cur, balo, bahi, bpk, min(j + 1, nk - 1), lr1b);
+            lds_order();
+            // (copies in vector registers: an instruction with a scalar-register operand issues at half rate)
+            float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cav), j));
+            float sn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, snv), j));
+            int sbv = __builtin_amdgcn_readlane(bpk, j) & 3;
+            asm volatile("v_mov_b32 %0, %0" : "+v"(ca));
+            asm volatile("v_mov_b32 %0, %0" : "+v"(sn));
+            asm volatile("v_mov_b32 %0, %0" : "+v"(sbv));
+            unsigned long long bits[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ix0 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].x, ca), SA_FMUL(pat[k].y, sn)));
+                const int iy0 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].x, sn), SA_FMUL(pat[k].y, ca)));
+                const int ix1 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].z, ca), SA_FMUL(pat[k].w, sn)));
+                const int iy1 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].z, sn), SA_FMUL(pat[k].w, ca)));
+                const int t0 = centre[iy0 * kPPitch + ix0 + sbv];
+                const int t1 = centre[iy1 * kPPitch + ix1 + sbv];
+                bits[k] = __ballot(t0 < t1);
             }
-            cur = nxt; x = xn; y = yn; l = ln; ok = okn;
+            write_lane8(dsc, bits, j);
+            lds_order();
         }
+    }
+    if (okv) {
+        uint4* out = reinterpret_cast<uint4*>(a.desc + ((size_t)b * a.capacity + i0 + lane) * 32);
+        out[0] = make_uint4(dsc[0], dsc[1], dsc[2], dsc[3]);
+        out[1] = make_uint4(dsc[4], dsc[5], dsc[6], dsc[7]);
     }
 }
 
@@ -1278,7 +1209,8 @@ int launch_describe(const DescribeArgs& a, int batch, hipStream_t st) {
     const long long blocks = (long long)div_up(a.capacity, kDescKps) * batch;
     if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "describe: capacity x batch too large for one launch");
     dim3 grid((unsigned)blocks);
-    hipLaunchKernelGGL(describe_kernel, grid, dim3(64), 0, st, d);
+    if (d.img0_aligned) hipLaunchKernelGGL(describe_kernel<true>, grid, dim3(64), 0, st, d);
+    else hipLaunchKernelGGL(describe_kernel<false>, grid, dim3(64), 0, st, d);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }
