@@ -103,6 +103,7 @@ struct slam_amd_extractor {
     };
     std::vector<PyrGroupPlan> pyr_groups;
     DevBuf pyr, blur, hist, tilecount, tilelist, sel, kpxy;
+    DevBuf lanegeom;                   // level geometry as a table in device memory: one level per lane of the describe kernel
     int select_keycap = 4096;          // kept survivors of a level ranked from LDS (debug knob)
     // host-call staging
     DevBuf h_img, h_kp, h_desc, h_count;
@@ -412,6 +413,20 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
     if ((rc = ex->tilelist.reserve(B * (size_t)g.total_tiles * kTileListCap * sizeof(uint32_t)))) return fail(rc);
     if ((rc = ex->sel.reserve(B * sizeof(FrameSelect)))) return fail(rc);
     if ((rc = ex->kpxy.reserve(B * (size_t)max_keypoints * sizeof(uint32_t)))) return fail(rc);
+    {
+        // rows: width, height, pitch, offset, scale (bit pattern), kMaxLevels entries each
+        int32_t lg[5 * kMaxLevels] = {};
+        for (int l = 0; l < g.nlevels; l++) {
+            lg[0 * kMaxLevels + l] = g.lv[l].w; lg[1 * kMaxLevels + l] = g.lv[l].h; lg[2 * kMaxLevels + l] = g.lv[l].pitch;
+            lg[3 * kMaxLevels + l] = (int32_t)g.lv[l].off; memcpy(&lg[4 * kMaxLevels + l], &g.lv[l].scale, 4);
+        }
+        if ((rc = ex->lanegeom.reserve(sizeof lg))) return fail(rc);
+        if (hipMemcpy(ex->lanegeom.p, lg, sizeof lg, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("upload of the level table failed");
+            return fail(SLAM_AMD_ERR_HIP);
+        }
+    }
     // packed positions start out as zeros: a slot that was never written decodes to (0, 0, level 0),
     // which the describe kernel rejects, instead of an arbitrary address
     if (hipMemset(ex->kpxy.p, 0, ex->kpxy.cap) != hipSuccess || hipMemset(ex->sel.p, 0, ex->sel.cap) != hipSuccess) {
@@ -429,7 +444,7 @@ extern "C" int slam_amd_extractor_destroy(slam_amd_extractor* ex) {
     if (!ex) return SLAM_AMD_OK;
     (void)hipSetDevice(ex->device);
     if (ex->stream) { (void)hipStreamSynchronize(ex->stream); (void)hipStreamDestroy(ex->stream); }
-    for (DevBuf* b : {&ex->tables, &ex->pyr, &ex->blur, &ex->hist, &ex->tilecount, &ex->tilelist, &ex->sel, &ex->kpxy,
+    for (DevBuf* b : {&ex->tables, &ex->pyr, &ex->blur, &ex->hist, &ex->tilecount, &ex->tilelist, &ex->sel, &ex->kpxy, &ex->lanegeom,
                       &ex->h_img, &ex->h_kp, &ex->h_desc, &ex->h_count})
         b->release();
     delete ex;
@@ -502,7 +517,7 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     DescribeArgs da;
     da.img0 = d_images; da.img0_frame_pitch = frame_pitch; da.img0_pitch = row_stride;
     da.img0_aligned = aligned; da.pyr = ex->pyr.as<uint8_t>(); da.blur = ex->blur.as<uint8_t>(); da.sel = ex->sel.as<FrameSelect>(); da.kp = d_kp;
-    da.kpxy = ex->kpxy.as<uint32_t>(); da.desc = d_desc; da.capacity = capacity; da.batch = batch; da.g = g;
+    da.kpxy = ex->kpxy.as<uint32_t>(); da.lanegeom = ex->lanegeom.as<int32_t>(); da.desc = d_desc; da.capacity = capacity; da.batch = batch; da.g = g;
     { ProfScope ps(kStageDescribe, st); if ((rc = launch_describe(da, batch, st))) return rc; }
     return SLAM_AMD_OK;
 }

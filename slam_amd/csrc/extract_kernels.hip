@@ -34,6 +34,21 @@
 #define SA_STAMP(i)
 #define SA_STAMP_PRINT
 #endif
+#ifndef SA_DESC_STAMPS
+#define SA_DESC_STAMPS 0  // 1: describe prints the clock at its pass boundaries for a few workgroups (timing experiments)
+#endif
+#if SA_DESC_STAMPS
+#define SA_DSTAMP_DECL unsigned long long dstamp_[8] = {}
+#define SA_DSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dstamp_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SA_DSTAMP_PRINT                                                                                   \
+    if (threadIdx.x == 0 && (blockIdx.x == 1000 || blockIdx.x == 5000 || blockIdx.x == 9000 || blockIdx.x == 14000)) \
+        printf("describe wg %d nk %d : %llu %llu %llu %llu %llu %llu\n", (int)blockIdx.x, nk, dstamp_[1] - dstamp_[0], \
+               dstamp_[2] - dstamp_[1], dstamp_[3] - dstamp_[2], dstamp_[4] - dstamp_[3], dstamp_[5] - dstamp_[4], dstamp_[6] - dstamp_[5])
+#else
+#define SA_DSTAMP_DECL
+#define SA_DSTAMP(i)
+#define SA_DSTAMP_PRINT
+#endif
 
 namespace sa {
 
@@ -929,22 +944,27 @@ __global__ __launch_bounds__(1024) void quadtree_select_kernel(SelectCompactArgs
 // nothing to do per keypoint, which matters: scalar instructions are not free on this
 // chip (a wave that issues one per two vector instructions already runs a quarter
 // slower than the vector instructions alone).
-//   pass 1  intensity centroid of every keypoint, the wave on one keypoint at a time
+//   pass 1  intensity centroid of every keypoint, the wave on one keypoint at a time:
+//           the 31 x 31 patch of the unblurred level arrives as one 16-byte load per
+//           lane (row lane / 2, columns 16 (lane % 2) ...) and never leaves the
+//           registers; a lane's 16 pixels meet constant byte weights (column numbers,
+//           0 outside the radius-15 disc; ones inside it) in v_dot4_u32_u8
 //   pass 2  angle, cos / sin, keypoint record: one keypoint per lane, once
-//   pass 3  256 rotated rBRIEF comparisons per keypoint, 4 per lane, assembled by ballot
-// A patch is staged in LDS by two 16-byte loads per lane -- rows of 48 bytes starting at
-// the 4-byte boundary at or before the patch's first column, (row, chunk) = (lane / 3,
-// lane % 3) and 21 rows further down, clamped to the last row -- 31 rows of the unblurred
-// level for pass 1 (radius-15 disc) and 37 of the blurred level for pass 3 (the rotated
-// pattern reaches at most 18 pixels).  The loads of the next keypoint are in flight
-// while the current one is processed.  Keypoints lie >= 31 pixels from the level border,
-// so both patches are inside the level, and the bytes a row's 48 reach beyond the patch
-// are inside the level buffer (never used).  No workgroup barrier is needed.
+//   pass 3  256 rotated rBRIEF comparisons per keypoint, 4 per lane, assembled by ballot,
+//           on the 37 x 37 patch of the blurred level (the rotated pattern reaches at most
+//           18 pixels), staged in LDS by two 16-byte loads per lane: rows of 48 bytes,
+//           (row, chunk) = (lane / 3, lane % 3) and 21 rows further down, clamped to the
+//           last row
+// The loads start at the patch's first column, whatever its alignment (the memory system
+// handles unaligned 16-byte loads), and those of the next keypoint are in flight while the
+// current one is processed.  Keypoints lie >= 31 pixels from the level border, so both
+// patches are inside the level; the bytes a row's 48 reach beyond the patch may run into
+// the next row, which exists (never used).  No workgroup barrier is needed.
 // ---------------------------------------------------------------------------
 constexpr int kURad = 15, kURows = 31;
 constexpr int kBRad = 18, kBRows = 37;
-constexpr int kPPitch = 48;        // LDS bytes per patch row
-constexpr int kPRows0 = 21;        // rows covered by the first load of a patch (63 lanes)
+constexpr int kPPitch = 48;        // LDS bytes per row of the blurred patch
+constexpr int kPRows0 = 21;        // rows covered by the first load of that patch (63 lanes)
 
 // rBRIEF sampling pattern as floats: x0, y0, x1, y1 of pair p at [4 * p].
 __constant__ __align__(16) float c_pattern[256 * 4] = {
@@ -954,10 +974,27 @@ __constant__ __align__(16) float c_pattern[256 * 4] = {
 // Half-width of row |v| of the radius-15 disc, 4 bits per row:
 // 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3 for |v| = 0 .. 15.  The disc is
 // symmetric, so the same table gives the half-height of column |u|.
-__device__ __forceinline__ int disc_half_width(int av) {
-    const unsigned long long packed = 0x3689ABCDDEEEFFFFull;
-    return (int)((packed >> (4 * av)) & 15u);
+constexpr int disc_half_width(int av) { return (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15u); }
+
+// Byte weights of pass 1.  Lane l holds pixels (row l / 2, columns 16 (l % 2) + 4 q + e) in byte e of
+// register q: w[l][q] the column numbers of the pixels inside the disc (0 outside), w[l][4 + q] ones
+// for them.
+struct DiscWeights { unsigned w[64][8]; };
+constexpr DiscWeights make_disc_weights() {
+    DiscWeights t = {};
+    for (int l = 0; l < 64; l++)
+        for (int q = 0; q < 4; q++)
+            for (int e = 0; e < 4; e++) {
+                const int r = l / 2, c = 16 * (l % 2) + 4 * q + e;
+                if (r >= kURows || c >= kURows) continue;
+                const int v = r - kURad, u = c - kURad;
+                if ((u < 0 ? -u : u) > disc_half_width(v < 0 ? -v : v)) continue;
+                t.w[l][q] |= (unsigned)c << (8 * e);
+                t.w[l][4 + q] |= 1u << (8 * e);
+            }
+    return t;
 }
+__constant__ __align__(16) DiscWeights c_disc = make_disc_weights();
 
 // Sum over the 64 lanes, left in lane 63: butterfly inside each row of 16 lanes, then the row
 // totals are passed up (rows 1 and 3 take the row before, rows 2 and 3 the half before).
@@ -990,34 +1027,41 @@ __device__ __forceinline__ void write_lane8(unsigned (&v)[8], const unsigned lon
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x4 __attribute__((aligned(4))) u32x4_a4;   // a 16-byte load from a 4-byte aligned address
-struct PatchRegs { u32x4 v0, v1; };
+typedef u32x4 __attribute__((aligned(1))) u32x4_a1;   // a 16-byte load from any address
+typedef const __attribute__((address_space(1))) uint8_t* global_bytes_t;
+typedef const __attribute__((address_space(1))) u32x4_a1* global_u4_t;
 
 #ifndef SA_DESC_KPS
 #define SA_DESC_KPS 8
 #endif
 constexpr int kDescKps = SA_DESC_KPS;                   // keypoints per (single-wave) workgroup
+#ifndef SA_DESC_AHEAD
+#define SA_DESC_AHEAD 4
+#endif
+constexpr int kDescAhead = SA_DESC_AHEAD < SA_DESC_KPS ? SA_DESC_AHEAD : SA_DESC_KPS;   // blurred patches in flight
 
-// AL0: the rows of the caller's image (level 0) are 4-byte aligned.  Otherwise the unblurred
-// patch of a level-0 keypoint is staged byte by byte.
-template <bool AL0>
 __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
     __shared__ __align__(16) uint8_t s_patch[kBRows * kPPitch];
     // 1-D grid, frame index fastest, so the workgroups beyond the last keypoint of
     // every frame (they exit at once) sit at the end of the grid.
+    SA_DSTAMP_DECL;
+    SA_DSTAMP(0);
     const int b = blockIdx.x % a.batch;
     const int i0 = (blockIdx.x / a.batch) * kDescKps;
     const int n = min(a.sel[b].total, a.capacity);
     if (i0 >= n) return;
     const int nk = min(kDescKps, n - i0);
     const int lane = threadIdx.x;
+    SA_DSTAMP(1);      // count known
     auto exchange = [](int from_lane, int v) { return __builtin_amdgcn_ds_bpermute(4 * from_lane, v); };
 
     // ---- per lane, once: geometry of level `lane`, then everything about keypoint `lane` ----
+    // (from a table in device memory: a per-lane read of the kernel arguments themselves is a vector
+    // load from the argument buffer, which need not be cached)
     int gw = 0, gh = 0, gpitch = 0, goff = 0, gscale = 0;
     if (lane < a.g.nlevels) {
-        const LevelGeom& Lg = a.g.lv[lane];
-        gw = Lg.w; gh = Lg.h; gpitch = Lg.pitch; goff = (int)Lg.off; gscale = __builtin_bit_cast(int, Lg.scale);
+        gw = a.lanegeom[lane]; gh = a.lanegeom[kMaxLevels + lane]; gpitch = a.lanegeom[2 * kMaxLevels + lane];
+        goff = a.lanegeom[3 * kMaxLevels + lane]; gscale = a.lanegeom[4 * kMaxLevels + lane];
     }
     uint32_t xyv = 0xffffffffu;                       // level 15: rejected
     if (lane < nk) xyv = a.kpxy[(size_t)b * a.capacity + i0 + lane];
@@ -1029,103 +1073,63 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
     const float lscale = __builtin_bit_cast(float, exchange(lsel, gscale));
     // The selection kernel only emits positions at least `edge` (>= 31) pixels from the border, so this
     // rejects nothing it wrote; it keeps a record that was never written (zeros) or a count that ran ahead
-    // of the records from becoming a wild read.  (24 = patch radius 18 + the up to 3 bytes of alignment;
-    // a row's 48 bytes may run past the level's right border into the next row, which exists.)
+    // of the records from becoming a wild read.  (24 = patch radius 18 and some; the 48 bytes of a row reach
+    // past the patch and may run past the level's right border into the next row, which then exists.)
     const bool okv = lvl_ok && !(px < 24 || py < 24 || px >= lw - 24 || py >= lh - 24);
-    const bool slowv = !AL0 && okv && pl == 0;
-    const unsigned slowbits = AL0 ? 0u : (unsigned)__ballot(slowv);
-    // First byte of the patches, moved back to a 4-byte boundary; the distance and the row pitch, packed.
-    // A lane without a valid keypoint points at the start of the frame's buffers with a row pitch of 0:
-    // the passes below run for it like for any other and its results are dropped at the end.
+    // First byte of either patch and the row pitch there.  A lane without a valid keypoint points at the
+    // start of the frame's buffers with a row pitch of 0: the passes below run for it like for any
+    // other and its results are dropped at the end.
     const uint8_t* ulevel = pl == 0 ? a.img0 + (size_t)b * a.img0_frame_pitch : a.pyr + (size_t)b * a.g.frame_bytes + loff;
-    const int upitch = pl == 0 ? a.img0_pitch : lpitch;
-    const uint8_t* up0 = ulevel + (ptrdiff_t)(py - kURad) * upitch + (px - kURad);
-    const unsigned su = slowv ? 0u : (unsigned)(reinterpret_cast<uintptr_t>(up0) & 3);
-    const uint8_t* bp0 = a.blur + (size_t)b * a.g.frame_bytes + loff + (ptrdiff_t)(py - kBRad) * lpitch + (px - kBRad);
-    const unsigned sb = (unsigned)(reinterpret_cast<uintptr_t>(bp0) & 3);
-    const unsigned long long uaddr = okv ? reinterpret_cast<uintptr_t>(up0) - su : reinterpret_cast<uintptr_t>(a.pyr + (size_t)b * a.g.frame_bytes);
-    const unsigned long long baddr = okv ? reinterpret_cast<uintptr_t>(bp0) - sb : reinterpret_cast<uintptr_t>(a.blur + (size_t)b * a.g.frame_bytes);
-    const int upk = okv ? (upitch << 2) | (int)su : 0;
-    const int bpk = okv ? (lpitch << 2) | (int)sb : 0;
+    const int upitch = okv ? (pl == 0 ? a.img0_pitch : lpitch) : 0;
+    const int bpitch = okv ? lpitch : 0;
+    const unsigned long long uaddr = reinterpret_cast<uintptr_t>(
+        okv ? ulevel + (ptrdiff_t)(py - kURad) * upitch + (px - kURad) : a.pyr + (size_t)b * a.g.frame_bytes);
+    const unsigned long long baddr = reinterpret_cast<uintptr_t>(
+        okv ? a.blur + (size_t)b * a.g.frame_bytes + loff + (ptrdiff_t)(py - kBRad) * lpitch + (px - kBRad)
+            : a.blur + (size_t)b * a.g.frame_bytes);
     const int ualo = (int)(unsigned)uaddr, uahi = (int)(unsigned)(uaddr >> 32);
     const int balo = (int)(unsigned)baddr, bahi = (int)(unsigned)(baddr >> 32);
-
-    // ---- per lane, once: its place in a patch ----
-    const int lr = lane / 3, lc = lane - 3 * lr;          // lane 63: row 21, which the second load covers too
-    const int lr1u = min(kPRows0 + lr, kURows - 1), lr1b = min(kPRows0 + lr, kBRows - 1);
-    uint8_t* const w0 = s_patch + lr * kPPitch + 16 * lc;
-    uint8_t* const w1u = s_patch + lr1u * kPPitch + 16 * lc;
-    uint8_t* const w1b = s_patch + lr1b * kPPitch + 16 * lc;
-    typedef const __attribute__((address_space(1))) uint8_t* global_bytes_t;
-    typedef const __attribute__((address_space(1))) u32x4_a4* global_u4_t;
     auto patch_base = [&](int alo, int ahi, int j) {
+#ifdef SA_DESC_EXP_SAMEPATCH
+        j = 0;      // timing experiment: every keypoint of the workgroup fetches the first one's patches
+#endif
         return (global_bytes_t)((unsigned long long)(unsigned)__builtin_amdgcn_readlane(alo, j) |
                                 ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ahi, j) << 32));
     };
-    auto patch_load = [&](PatchRegs& r, int alo, int ahi, int pk, int j, int lr1) {
-        global_bytes_t base = patch_base(alo, ahi, j);
-        const int pitch = __builtin_amdgcn_readlane(pk, j) >> 2;
-        r.v0 = *(global_u4_t)(base + (__umul24((unsigned)lr, (unsigned)pitch) + 16u * (unsigned)lc));
-        r.v1 = *(global_u4_t)(base + (__umul24((unsigned)lr1, (unsigned)pitch) + 16u * (unsigned)lc));
-    };
-    auto patch_store = [&](const PatchRegs& r, uint8_t* w1) {
-        *reinterpret_cast<u32x4*>(w0) = r.v0;
-        *reinterpret_cast<u32x4*>(w1) = r.v1;
-    };
-    // LDS traffic of one wave executes in order; this only keeps the compiler from moving LDS
-    // reads and writes across it.
-    auto lds_order = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
 
+    SA_DSTAMP(2);      // keypoints and geometry known
     // ---- pass 1: intensity centroid, one keypoint at a time ----
-    // Lanes 0-30 own the columns u = -15..15 for the rows v = -15..0, lanes 32-62 the
-    // same columns for v = 1..15.  A lane adds up its column (rows outside the disc
-    // masked off) and the row-weighted sum; the column weight is applied once.
+    // m10 = sum of (column - 15) x pixel, m01 = sum of (row - 15) x pixel over the disc.
     int m10v = 0, m01v = 0;     // moments of keypoint `lane`
     {
-        const int col = lane & 31, half = lane >> 5;
-        const int u = col - 15;
-        const int vlim = col < 31 ? disc_half_width(u < 0 ? -u : u) : -1;  // |v| <= vlim is inside
-        const int vbase = half ? 1 : -15;                                  // v = vbase + vv, vv = 0..15
-        const int lo = half ? 0 : 15 - vlim, hi = half ? vlim - 1 : 15;    // vv range inside the disc
-        const unsigned rows = hi >= lo ? (2u << hi) - (1u << lo) : 0u;
-        // column 31 (u = 16) and row v = 16 are masked off; their reads stay inside s_patch
-        const uint8_t* col0 = s_patch + (kURad + vbase) * kPPitch + kURad + u;
-        PatchRegs cur;
-        patch_load(cur, ualo, uahi, upk, 0, lr1u);
-#pragma unroll 1
-        for (int j = 0; j < nk; j++) {
-            if (!AL0 && ((slowbits >> j) & 1u)) {
-                global_bytes_t p0 = patch_base(ualo, uahi, j);
-                const int pitch = __builtin_amdgcn_readlane(upk, j) >> 2;
-                for (int k = lane; k < kURows * kURows; k += 64) {
-                    const int r = k / kURows, c = k - r * kURows;
-                    s_patch[r * kPPitch + c] = p0[(size_t)r * pitch + c];
-                }
-            } else {
-                patch_store(cur, w1u);
-            }
-            // the next keypoint's loads go out before this one's arithmetic (the last one is fetched twice)
-            patch_load(cur, ualo, uahi, upk, min(j + 1, nk - 1), lr1u);
-            lds_order();
-            const uint8_t* colp = col0 + (__builtin_amdgcn_readlane(upk, j) & 3);
-            int colsum = 0, vsum = 0;
+        const u32x4 wc = *reinterpret_cast<const u32x4*>(&c_disc.w[lane][0]);
+        const u32x4 wm = *reinterpret_cast<const u32x4*>(&c_disc.w[lane][4]);
+        const int urow = min(lane >> 1, kURows - 1), ucol = 16 * (lane & 1);   // lanes 62, 63: row 30 again, weights 0
+        const int vrow = (lane >> 1) - kURad;
+        auto load_u = [&](int j) {
+            const int pitch = __builtin_amdgcn_readlane(upitch, j);
+            return *(global_u4_t)(patch_base(ualo, uahi, j) + (__umul24((unsigned)urow, (unsigned)pitch) + (unsigned)ucol));
+        };
+        // every keypoint's load goes out before the first one's arithmetic (slots beyond the last keypoint
+        // repeat it; their results land in lanes that hold no keypoint)
+        u32x4 up[kDescKps];
 #pragma unroll
-            for (int vv = 0; vv < 16; vv++) {
-                int val = colp[vv * kPPitch];
-                val &= ((int)(rows << (31 - vv))) >> 31;
-                colsum += val;
-                vsum += vv * val;
+        for (int j = 0; j < kDescKps; j++) up[j] = load_u(min(j, nk - 1));
+#pragma unroll
+        for (int j = 0; j < kDescKps; j++) {
+            const u32x4 p = up[j];
+            unsigned wsum = 0, sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                wsum = __builtin_amdgcn_udot4(p[q], wc[q], wsum, false);
+                sum = __builtin_amdgcn_udot4(p[q], wm[q], sum, false);
             }
-            const int m10 = __builtin_amdgcn_readlane(wave_sum_to_lane63(u * colsum), 63);
-            const int m01 = __builtin_amdgcn_readlane(wave_sum_to_lane63(vbase * colsum + vsum), 63);
+            const int m10 = __builtin_amdgcn_readlane(wave_sum_to_lane63((int)wsum + __mul24((int)sum, -kURad)), 63);
+            const int m01 = __builtin_amdgcn_readlane(wave_sum_to_lane63(__mul24(vrow, (int)sum)), 63);
             write_lane2(m10v, m01v, m10, m01, j);
-            lds_order();   // the next keypoint's patch overwrites s_patch: reads first
         }
     }
+    SA_DSTAMP(3);      // pass 1 done
     // ---- pass 2: angle, cos and sin, keypoint record: every keypoint in its own lane ----
     float cav = 0.f, snv = 0.f;
     if (okv) {
@@ -1137,47 +1141,83 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
         kp->y = SA_FMUL((float)py, lscale);
         kp->angle = angle;
     }
+    SA_DSTAMP(4);      // pass 2 done
     // ---- pass 3: rBRIEF, pair p = 64*k + lane, k = 0..3; ballot k holds bytes 8k..8k+7 ----
     unsigned dsc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // descriptor of keypoint `lane`
     {
         float4 pat[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const float4*>(c_pattern)[64 * k + lane];
-        const uint8_t* centre = s_patch + kBRad * kPPitch + kBRad;
-        PatchRegs cur;
-        patch_load(cur, balo, bahi, bpk, 0, lr1b);
-#pragma unroll 1
-        for (int j = 0; j < nk; j++) {
-            patch_store(cur, w1b);
-            patch_load(cur, balo, bahi, bpk, min(j + 1, nk - 1), lr1b);
+        const int lr = lane / 3, lc = lane - 3 * lr;          // lane 63: row 21, which the second load covers too
+        const int lr1 = min(kPRows0 + lr, kBRows - 1);
+        const bool second_rows = kPRows0 + lr < kBRows;       // lanes 0-47
+        uint8_t* const w0 = s_patch + lr * kPPitch + 16 * lc;
+        uint8_t* const w1 = s_patch + lr1 * kPPitch + 16 * lc;
+        struct PatchRegs { u32x4 v0, v1; };
+        auto load_b = [&](int j) {
+            global_bytes_t base = patch_base(balo, bahi, j);
+            const int pitch = __builtin_amdgcn_readlane(bpitch, j);
+            PatchRegs r;
+            r.v0 = *(global_u4_t)(base + (__umul24((unsigned)lr, (unsigned)pitch) + 16u * (unsigned)lc));
+            // (the address unit spends a cycle per lane on these loads: the lanes past the last row stay out)
+            if (second_rows) r.v1 = *(global_u4_t)(base + (__umul24((unsigned)lr1, (unsigned)pitch) + 16u * (unsigned)lc));
+            return r;
+        };
+        // LDS traffic of one wave executes in order; this only keeps the compiler from moving LDS
+        // reads and writes across it.
+        auto lds_order = [] {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        // Rounding to the nearest integer, ties to even, as the low bits of x + 1.5 * 2^23; the sum's bit
+        // pattern is 0x4B400000 + the integer.  Row * pitch + column on the low 24 bits of the patterns,
+        // the two offsets taken off at the end (together with the patch centre's place in s_patch).
+        constexpr float kMagic = 12582912.0f;
+        constexpr unsigned kMagicBits = 0x4B400000u;
+        constexpr unsigned kUnbias = (kMagicBits & 0xffffffu) * kPPitch + kMagicBits - (kBRad * kPPitch + kBRad);
+        const unsigned s_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_patch - kUnbias;
+        auto sample_at = [&](float fx, float fy) -> int {
+            const unsigned bx = __builtin_bit_cast(unsigned, SA_FADD(fx, kMagic)), by = __builtin_bit_cast(unsigned, SA_FADD(fy, kMagic));
+            const unsigned at = __umul24(by, (unsigned)kPPitch) + bx + s_base;
+            return *(__attribute__((address_space(3))) const uint8_t*)(uintptr_t)at;
+        };
+        // kDescAhead patches are in flight ahead of the one being sampled
+        PatchRegs ahead[kDescAhead];
+#pragma unroll
+        for (int d = 0; d < kDescAhead; d++) ahead[d] = load_b(min(d, nk - 1));
+#pragma unroll
+        for (int j = 0; j < kDescKps; j++) {
+            *reinterpret_cast<u32x4*>(w0) = ahead[j % kDescAhead].v0;
+            if (second_rows) *reinterpret_cast<u32x4*>(w1) = ahead[j % kDescAhead].v1;
+            if (j + kDescAhead < kDescKps) ahead[j % kDescAhead] = load_b(min(j + kDescAhead, nk - 1));
             lds_order();
             // (copies in vector registers: an instruction with a scalar-register operand issues at half rate)
             float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cav), j));
             float sn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, snv), j));
-            int sbv = __builtin_amdgcn_readlane(bpk, j) & 3;
             asm volatile("v_mov_b32 %0, %0" : "+v"(ca));
             asm volatile("v_mov_b32 %0, %0" : "+v"(sn));
-            asm volatile("v_mov_b32 %0, %0" : "+v"(sbv));
             unsigned long long bits[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int ix0 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].x, ca), SA_FMUL(pat[k].y, sn)));
-                const int iy0 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].x, sn), SA_FMUL(pat[k].y, ca)));
-                const int ix1 = SA_RINT_I(SA_FSUB(SA_FMUL(pat[k].z, ca), SA_FMUL(pat[k].w, sn)));
-                const int iy1 = SA_RINT_I(SA_FADD(SA_FMUL(pat[k].z, sn), SA_FMUL(pat[k].w, ca)));
-                const int t0 = centre[iy0 * kPPitch + ix0 + sbv];
-                const int t1 = centre[iy1 * kPPitch + ix1 + sbv];
+                const int t0 = sample_at(SA_FSUB(SA_FMUL(pat[k].x, ca), SA_FMUL(pat[k].y, sn)),
+                                         SA_FADD(SA_FMUL(pat[k].x, sn), SA_FMUL(pat[k].y, ca)));
+                const int t1 = sample_at(SA_FSUB(SA_FMUL(pat[k].z, ca), SA_FMUL(pat[k].w, sn)),
+                                         SA_FADD(SA_FMUL(pat[k].z, sn), SA_FMUL(pat[k].w, ca)));
                 bits[k] = __ballot(t0 < t1);
             }
             write_lane8(dsc, bits, j);
-            lds_order();
+            lds_order();   // the next keypoint's patch overwrites s_patch: reads first
         }
     }
+    SA_DSTAMP(5);      // pass 3 done
     if (okv) {
         uint4* out = reinterpret_cast<uint4*>(a.desc + ((size_t)b * a.capacity + i0 + lane) * 32);
         out[0] = make_uint4(dsc[0], dsc[1], dsc[2], dsc[3]);
         out[1] = make_uint4(dsc[4], dsc[5], dsc[6], dsc[7]);
     }
+    SA_DSTAMP(6);
+    SA_DSTAMP_PRINT;
 }
 
 // ---------------------------------------------------------------------------
@@ -1209,8 +1249,7 @@ int launch_describe(const DescribeArgs& a, int batch, hipStream_t st) {
     const long long blocks = (long long)div_up(a.capacity, kDescKps) * batch;
     if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "describe: capacity x batch too large for one launch");
     dim3 grid((unsigned)blocks);
-    if (d.img0_aligned) hipLaunchKernelGGL(describe_kernel<true>, grid, dim3(64), 0, st, d);
-    else hipLaunchKernelGGL(describe_kernel<false>, grid, dim3(64), 0, st, d);
+    hipLaunchKernelGGL(describe_kernel, grid, dim3(64), 0, st, d);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }
