@@ -952,19 +952,18 @@ __global__ __launch_bounds__(1024) void quadtree_select_kernel(SelectCompactArgs
 //   pass 2  angle, cos / sin, keypoint record: one keypoint per lane, once
 //   pass 3  256 rotated rBRIEF comparisons per keypoint, 4 per lane, assembled by ballot,
 //           on the 37 x 37 patch of the blurred level (the rotated pattern reaches at most
-//           18 pixels), staged in LDS by two 16-byte loads per lane: rows of 48 bytes,
-//           (row, chunk) = (lane / 3, lane % 3) and 21 rows further down, clamped to the
-//           last row
-// The loads start at the patch's first column, whatever its alignment (the memory system
-// handles unaligned 16-byte loads), and those of the next keypoint are in flight while the
-// current one is processed.  Keypoints lie >= 31 pixels from the level border, so both
-// patches are inside the level; the bytes a row's 48 reach beyond the patch may run into
-// the next row, which exists (never used).  No workgroup barrier is needed.
+//           18 pixels), staged in LDS by three 16-byte loads per lane: rows of 64 bytes
+//           from the 16-byte boundary before the patch, (row, chunk) = (lane / 4, lane % 4)
+// The unblurred patch is fetched at its own alignment (the memory system handles unaligned
+// 16-byte loads, at a cycle per lane in the address unit), and the loads of the next
+// keypoints are in flight while the current one is processed.  Keypoints lie >= 31 pixels
+// from the level border, so both patches are inside the level; the bytes a row's 64 reach
+// beyond the patch are inside the level's rows, which are 64-byte aligned (never used).
+// No workgroup barrier is needed.
 // ---------------------------------------------------------------------------
 constexpr int kURad = 15, kURows = 31;
 constexpr int kBRad = 18, kBRows = 37;
-constexpr int kPPitch = 48;        // LDS bytes per row of the blurred patch
-constexpr int kPRows0 = 21;        // rows covered by the first load of that patch (63 lanes)
+constexpr int kPPitch = 64;        // LDS bytes per row of the blurred patch
 
 // rBRIEF sampling pattern as floats: x0, y0, x1, y1 of pair p at [4 * p].
 __constant__ __align__(16) float c_pattern[256 * 4] = {
@@ -1084,9 +1083,11 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
     const int bpitch = okv ? lpitch : 0;
     const unsigned long long uaddr = reinterpret_cast<uintptr_t>(
         okv ? ulevel + (ptrdiff_t)(py - kURad) * upitch + (px - kURad) : a.pyr + (size_t)b * a.g.frame_bytes);
-    const unsigned long long baddr = reinterpret_cast<uintptr_t>(
+    const unsigned long long bfirst = reinterpret_cast<uintptr_t>(
         okv ? a.blur + (size_t)b * a.g.frame_bytes + loff + (ptrdiff_t)(py - kBRad) * lpitch + (px - kBRad)
             : a.blur + (size_t)b * a.g.frame_bytes);
+    const unsigned long long baddr = bfirst & ~15ull;     // the blurred patch is fetched from the 16-byte boundary before it
+    const int bshift = (int)(bfirst & 15ull);
     const int ualo = (int)(unsigned)uaddr, uahi = (int)(unsigned)(uaddr >> 32);
     const int balo = (int)(unsigned)baddr, bahi = (int)(unsigned)(baddr >> 32);
     auto patch_base = [&](int alo, int ahi, int j) {
@@ -1148,19 +1149,23 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
         float4 pat[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const float4*>(c_pattern)[64 * k + lane];
-        const int lr = lane / 3, lc = lane - 3 * lr;          // lane 63: row 21, which the second load covers too
-        const int lr1 = min(kPRows0 + lr, kBRows - 1);
-        const bool second_rows = kPRows0 + lr < kBRows;       // lanes 0-47
-        uint8_t* const w0 = s_patch + lr * kPPitch + 16 * lc;
-        uint8_t* const w1 = s_patch + lr1 * kPPitch + 16 * lc;
-        struct PatchRegs { u32x4 v0, v1; };
+        // Rows of 64 bytes that start at the 16-byte boundary at or before the patch's first column (the
+        // address unit takes four aligned 16-byte lanes of one line per cycle, but one lane at a time where
+        // they are not aligned); lane = 4 x row + chunk, 16 rows per load, the third load rows 32-36.
+        // The rows of the blurred level are 64-byte aligned, so the patch starts at the same column
+        // of every row of s_patch.
+        const int brow = lane >> 2, bchunk = lane & 3;
+        const bool third_rows = 2 * 16 + brow < kBRows;           // lanes 0-19
+        uint8_t* const w0 = s_patch + 16 * lane;
+        struct PatchRegs { u32x4 v0, v1, v2; };
         auto load_b = [&](int j) {
             global_bytes_t base = patch_base(balo, bahi, j);
-            const int pitch = __builtin_amdgcn_readlane(bpitch, j);
+            const unsigned pitch = (unsigned)__builtin_amdgcn_readlane(bpitch, j);
+            const unsigned at = __umul24((unsigned)brow, pitch) + 16u * (unsigned)bchunk;
             PatchRegs r;
-            r.v0 = *(global_u4_t)(base + (__umul24((unsigned)lr, (unsigned)pitch) + 16u * (unsigned)lc));
-            // (the address unit spends a cycle per lane on these loads: the lanes past the last row stay out)
-            if (second_rows) r.v1 = *(global_u4_t)(base + (__umul24((unsigned)lr1, (unsigned)pitch) + 16u * (unsigned)lc));
+            r.v0 = *(global_u4_t)(base + at);
+            r.v1 = *(global_u4_t)(base + (at + 16u * pitch));
+            if (third_rows) r.v2 = *(global_u4_t)(base + (at + 32u * pitch));
             return r;
         };
         // LDS traffic of one wave executes in order; this only keeps the compiler from moving LDS
@@ -1171,15 +1176,15 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
         // Rounding to the nearest integer, ties to even, as the low bits of x + 1.5 * 2^23; the sum's bit
-        // pattern is 0x4B400000 + the integer.  Row * pitch + column on the low 24 bits of the patterns,
-        // the two offsets taken off at the end (together with the patch centre's place in s_patch).
+        // pattern is 0x4B400000 + the integer.  Row * 64 + column on the patterns themselves, the two
+        // offsets taken off at the end (together with the patch centre's place in s_patch).
         constexpr float kMagic = 12582912.0f;
         constexpr unsigned kMagicBits = 0x4B400000u;
-        constexpr unsigned kUnbias = (kMagicBits & 0xffffffu) * kPPitch + kMagicBits - (kBRad * kPPitch + kBRad);
+        constexpr unsigned kUnbias = (kMagicBits << 6) + kMagicBits - (unsigned)(kBRad * kPPitch + kBRad);
         const unsigned s_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_patch - kUnbias;
-        auto sample_at = [&](float fx, float fy) -> int {
+        auto sample_at = [&](float fx, float fy, unsigned origin) -> int {
             const unsigned bx = __builtin_bit_cast(unsigned, SA_FADD(fx, kMagic)), by = __builtin_bit_cast(unsigned, SA_FADD(fy, kMagic));
-            const unsigned at = __umul24(by, (unsigned)kPPitch) + bx + s_base;
+            const unsigned at = (by << 6) + bx + origin;
             return *(__attribute__((address_space(3))) const uint8_t*)(uintptr_t)at;
         };
         // kDescAhead patches are in flight ahead of the one being sampled
@@ -1189,21 +1194,24 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
 #pragma unroll
         for (int j = 0; j < kDescKps; j++) {
             *reinterpret_cast<u32x4*>(w0) = ahead[j % kDescAhead].v0;
-            if (second_rows) *reinterpret_cast<u32x4*>(w1) = ahead[j % kDescAhead].v1;
+            *reinterpret_cast<u32x4*>(w0 + 1024) = ahead[j % kDescAhead].v1;
+            if (third_rows) *reinterpret_cast<u32x4*>(w0 + 2048) = ahead[j % kDescAhead].v2;
             if (j + kDescAhead < kDescKps) ahead[j % kDescAhead] = load_b(min(j + kDescAhead, nk - 1));
             lds_order();
             // (copies in vector registers: an instruction with a scalar-register operand issues at half rate)
             float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cav), j));
             float sn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, snv), j));
+            unsigned origin = s_base + (unsigned)__builtin_amdgcn_readlane(bshift, j);
             asm volatile("v_mov_b32 %0, %0" : "+v"(ca));
             asm volatile("v_mov_b32 %0, %0" : "+v"(sn));
+            asm volatile("v_mov_b32 %0, %0" : "+v"(origin));
             unsigned long long bits[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int t0 = sample_at(SA_FSUB(SA_FMUL(pat[k].x, ca), SA_FMUL(pat[k].y, sn)),
-                                         SA_FADD(SA_FMUL(pat[k].x, sn), SA_FMUL(pat[k].y, ca)));
+                                         SA_FADD(SA_FMUL(pat[k].x, sn), SA_FMUL(pat[k].y, ca)), origin);
                 const int t1 = sample_at(SA_FSUB(SA_FMUL(pat[k].z, ca), SA_FMUL(pat[k].w, sn)),
-                                         SA_FADD(SA_FMUL(pat[k].z, sn), SA_FMUL(pat[k].w, ca)));
+                                         SA_FADD(SA_FMUL(pat[k].z, sn), SA_FMUL(pat[k].w, ca)), origin);
                 bits[k] = __ballot(t0 < t1);
             }
             write_lane8(dsc, bits, j);
