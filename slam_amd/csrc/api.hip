@@ -103,6 +103,7 @@ struct slam_amd_extractor {
     };
     std::vector<PyrGroupPlan> pyr_groups;
     DevBuf pyr, blur, hist, tilecount, tilelist, sel, kpxy;
+    DevBuf tiledesc;                   // level and tile coordinates of every FAST tile of a frame
     DevBuf lanegeom;                   // level geometry as a table in device memory: one level per lane of the describe kernel
     int select_keycap = 4096;          // kept survivors of a level ranked from LDS (debug knob)
     // host-call staging
@@ -414,6 +415,23 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
     if ((rc = ex->sel.reserve(B * sizeof(FrameSelect)))) return fail(rc);
     if ((rc = ex->kpxy.reserve(B * (size_t)max_keypoints * sizeof(uint32_t)))) return fail(rc);
     {
+        // the FAST kernel finds its tile by one table read instead of a search over the levels and a division
+        std::vector<uint32_t> td((size_t)g.total_tiles);
+        for (int l = 0; l < g.nlevels; l++) {
+            const int nty = div_up(g.lv[l].h, kFastTileH);
+            if (g.lv[l].tiles_x > 0xfff || nty > 0xffff) return fail((set_error("level too large for the tile table"), SLAM_AMD_ERR_ARG));
+            for (int ty = 0; ty < nty; ty++)
+                for (int tx = 0; tx < g.lv[l].tiles_x; tx++)
+                    td[(size_t)g.lv[l].tile_base + (size_t)ty * g.lv[l].tiles_x + tx] = (uint32_t)l | ((uint32_t)tx << 4) | ((uint32_t)ty << 16);
+        }
+        if ((rc = ex->tiledesc.reserve(td.size() * sizeof(uint32_t)))) return fail(rc);
+        if (hipMemcpy(ex->tiledesc.p, td.data(), td.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("upload of the tile table failed");
+            return fail(SLAM_AMD_ERR_HIP);
+        }
+    }
+    {
         // rows: width, height, pitch, offset, scale (bit pattern), kMaxLevels entries each
         int32_t lg[5 * kMaxLevels] = {};
         for (int l = 0; l < g.nlevels; l++) {
@@ -444,7 +462,7 @@ extern "C" int slam_amd_extractor_destroy(slam_amd_extractor* ex) {
     if (!ex) return SLAM_AMD_OK;
     (void)hipSetDevice(ex->device);
     if (ex->stream) { (void)hipStreamSynchronize(ex->stream); (void)hipStreamDestroy(ex->stream); }
-    for (DevBuf* b : {&ex->tables, &ex->pyr, &ex->blur, &ex->hist, &ex->tilecount, &ex->tilelist, &ex->sel, &ex->kpxy, &ex->lanegeom,
+    for (DevBuf* b : {&ex->tables, &ex->pyr, &ex->blur, &ex->hist, &ex->tilecount, &ex->tilelist, &ex->sel, &ex->kpxy, &ex->lanegeom, &ex->tiledesc,
                       &ex->h_img, &ex->h_kp, &ex->h_desc, &ex->h_count})
         b->release();
     delete ex;
@@ -507,7 +525,7 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     fa.img0 = d_images; fa.img0_frame_pitch = frame_pitch; fa.img0_pitch = row_stride; fa.img0_aligned = aligned;
     fa.pyr = ex->pyr.as<uint8_t>(); fa.blur = ex->blur.as<uint8_t>(); fa.hist = ex->hist.as<unsigned>();
     fa.tilecount = ex->tilecount.as<unsigned>(); fa.tilelist = ex->tilelist.as<uint32_t>(); fa.g = g;
-    fa.grid_shift = ex->grid_shift; fa.tiles_all = 0; fa.tiles_per_xcd = 0;
+    fa.grid_shift = ex->grid_shift; fa.tiledesc = ex->tiledesc.as<uint32_t>(); fa.tiles_eighth = 0;
     { ProfScope ps(kStageFast, st); if ((rc = launch_fast(fa, batch, st))) return rc; }
     SelectCompactArgs sc;
     sc.hist = ex->hist.as<unsigned>(); sc.tilecount = ex->tilecount.as<unsigned>(); sc.tilelist = ex->tilelist.as<uint32_t>();

@@ -168,21 +168,18 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     static_assert(kListBytes <= (int)sizeof(s_scratch), "list 1 must fit the scratch region");
     constexpr int P = kImgPitch;
 
-    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  XCD k
-    // takes the k-th contiguous eighth of all (frame, tile) pairs, so tiles that share
-    // halo lines run on the same L2 instead of fetching them once per XCD.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int g = xcd * a.tiles_per_xcd + slot;
-    if (g >= a.tiles_all) return;
-    const int b = g / a.g.total_tiles;
-    const int ftile = g - b * a.g.total_tiles;
-    int l = 0;
-#pragma unroll 1
-    for (int i = 1; i < a.g.nlevels; i++)
-        if (ftile >= a.g.lv[i].tile_base) l = i;
+    // Grid: x = tile slot of a frame (a multiple of 8 of them), y = frame.  Workgroups are dealt
+    // round-robin over the 8 XCDs, each with its own L2, in x-fastest order, so XCD k sees the slots
+    // with x % 8 == k: it takes the k-th contiguous eighth of every frame's tiles, and tiles that
+    // share halo lines run on the same L2 instead of fetching them once per XCD.  The tile's level
+    // and place come from a table: no search over the levels, no division (scalar instructions
+    // take issue cycles from the vector ones, and every wave of the workgroup repeats them).
+    const int b = blockIdx.y;
+    const int ftile = (int)(blockIdx.x & 7u) * a.tiles_eighth + (int)(blockIdx.x >> 3);
+    if (ftile >= a.g.total_tiles) return;
+    const uint32_t td = a.tiledesc[ftile];
+    const int l = (int)(td & 15u), txi = (int)((td >> 4) & 0xfffu), tyi = (int)(td >> 16);
     const LevelGeom& L = a.g.lv[l];
-    const int tile = ftile - L.tile_base;
-    const int tyi = tile / L.tiles_x, txi = tile - tyi * L.tiles_x;
     const int x0 = txi * kFastTileW, y0 = tyi * kFastTileH;
     const int w = L.w, h = L.h;
     const uint8_t* img;
@@ -1233,9 +1230,9 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
 // ---------------------------------------------------------------------------
 int launch_fast(const FastArgs& a0, int batch, hipStream_t st) {
     FastArgs a = a0;
-    a.tiles_all = a.g.total_tiles * batch;
-    a.tiles_per_xcd = div_up(a.tiles_all, 8);
-    dim3 grid(a.tiles_per_xcd * 8);
+    a.tiles_eighth = div_up(a.g.total_tiles, 8);
+    if (batch > 65535) SA_FAIL(SLAM_AMD_ERR_ARG, "fast: batch too large for one launch");
+    dim3 grid(a.tiles_eighth * 8, batch);
     hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;

@@ -36,8 +36,8 @@ struct FastArgs {
     unsigned* tilecount;  // [batch][total_tiles] NMS survivors of every FAST tile
     uint32_t* tilelist;   // [batch][total_tiles][kTileListCap] lx | ly << 6 | score << 16, any order
     int grid_shift;       // 0: off; 3, 4, 5: keep the best survivor of every 8, 16, 32 pixel cell
-    int tiles_all;        // total_tiles * batch (set by the launcher)
-    int tiles_per_xcd;    // ceil(tiles_all / 8)
+    const uint32_t* tiledesc;  // [total_tiles] level | tile column << 4 | tile row << 16 of every FAST tile of a frame (device memory)
+    int tiles_eighth;     // ceil(total_tiles / 8) (set by the launcher)
     PyrGeom g;
 };
 
