@@ -39,7 +39,7 @@ if trace:
         gmax = max(g for g, t in v)
         sel = [t for g, t in v if g == gmax]
         out.append("%-62s %7d %12.2f" % (k, len(sel), sum(sel) / len(sel)))
-for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mem"):
     files = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))
     if not files:
         continue
@@ -61,7 +61,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
 if len(sys.argv) > 2:
     rec = {"kernels": {}}
     vals = collections.defaultdict(dict)
-    for name, only in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_sq", None), ("pmc_sq2", None)):
+    for name, only in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_sq", None), ("pmc_sq2", None), ("pmc_mem", None)):
         files = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))
         if not files:
             continue
