@@ -33,9 +33,6 @@ constexpr int kMmBlock = 256;                 // 4 waves
 #ifndef SA_MM_NB
 #define SA_MM_NB 2
 #endif
-#ifndef SA_MM_KUNROLL
-#define SA_MM_KUNROLL 2
-#endif
 constexpr int kMmNB = SA_MM_NB;               // query blocks of 32 per wave
 constexpr int kMmQueries = 4 * kMmNB * 32;    // queries per workgroup
 constexpr int kMmSub = 32;                    // train rows of one product
@@ -177,25 +174,42 @@ __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
 
     int buf = 0;
     int blockno = 0;
+    // LDS byte address of this lane's operand slice of buffer 0, block 0, step 0
+    const unsigned tile_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint4*)&s_tile[0][0] + (unsigned)((h * 32 + r) * 16);
     for (int t0 = t_begin; t0 < t_end; t0 += kMmTile) {
         const bool more = t0 + kMmTile < t_end;
         unsigned wnext[2] = {0u, 0u};
         if (more) load_tile(t0 + kMmTile, wnext);
-#pragma unroll SA_MM_KUNROLL
+        // The nine train-side operands of a block of 32 rows are read ahead of its products: those of
+        // the tile's first block before any product, those of the second block one by one as the first
+        // block's registers fall free.  (Read just before use, every pair of products waits for the
+        // LDS round trip and the matrix pipe runs dry in between.)  The reads and the waits for them
+        // are written out because the compiler would pair each read with its use again; LDS operations
+        // complete in order, so "at most n still outstanding" covers the one a product needs, and
+        // any LDS operation the compiler puts in between only makes a wait stricter.
+        v4i af[kMmSteps];
+        const unsigned a_addr = tile_addr + (unsigned)buf * (unsigned)(2 * kMmSubU4 * 16);
+#pragma unroll
+        for (int s = 0; s < kMmSteps; s++)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[s]) : "v"(a_addr), "n"(s * 1024));
+#pragma unroll
         for (int k = 0; k < 2; k++) {
             v16i acc[kMmNB];
 #pragma unroll
             for (int b = 0; b < kMmNB; b++)
 #pragma unroll
                 for (int i = 0; i < 16; i++) acc[b][i] = 0;
-            const uint4* tile = s_tile[buf] + k * kMmSubU4;
 #pragma unroll
             for (int s = 0; s < kMmSteps; s++) {
-                const uint4 t4 = tile[(s * 2 + h) * 32 + r];
-                const v4i af = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
+                if (k == 0) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(af[s]));
+                else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af[s]) : "n"(kMmSteps - 1 - s));
 #pragma unroll
                 for (int b = 0; b < kMmNB; b++)
-                    acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, s < 8 ? bq[b][s] : b_tail, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], s < 8 ? bq[b][s] : b_tail, acc[b], 0, 0, 0);
+                if (k == 0) {
+                    // the same step of the second block
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[s]) : "v"(a_addr), "n"(kMmSubU4 * 16 + s * 1024));
+                }
             }
 #pragma unroll
             for (int b = 0; b < kMmNB; b++) {
