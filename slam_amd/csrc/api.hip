@@ -432,11 +432,11 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
         }
     }
     {
-        // rows: width, height, pitch, offset, scale (bit pattern), kMaxLevels entries each
-        int32_t lg[5 * kMaxLevels] = {};
+        // per level: width, height, pitch, offset, scale (bit pattern), three zeros
+        int32_t lg[8 * kMaxLevels] = {};
         for (int l = 0; l < g.nlevels; l++) {
-            lg[0 * kMaxLevels + l] = g.lv[l].w; lg[1 * kMaxLevels + l] = g.lv[l].h; lg[2 * kMaxLevels + l] = g.lv[l].pitch;
-            lg[3 * kMaxLevels + l] = (int32_t)g.lv[l].off; memcpy(&lg[4 * kMaxLevels + l], &g.lv[l].scale, 4);
+            lg[8 * l + 0] = g.lv[l].w; lg[8 * l + 1] = g.lv[l].h; lg[8 * l + 2] = g.lv[l].pitch;
+            lg[8 * l + 3] = (int32_t)g.lv[l].off; memcpy(&lg[8 * l + 4], &g.lv[l].scale, 4);
         }
         if ((rc = ex->lanegeom.reserve(sizeof lg))) return fail(rc);
         if (hipMemcpy(ex->lanegeom.p, lg, sizeof lg, hipMemcpyHostToDevice) != hipSuccess) {

@@ -1056,8 +1056,8 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
     // load from the argument buffer, which need not be cached)
     int gw = 0, gh = 0, gpitch = 0, goff = 0, gscale = 0;
     if (lane < a.g.nlevels) {
-        gw = a.lanegeom[lane]; gh = a.lanegeom[kMaxLevels + lane]; gpitch = a.lanegeom[2 * kMaxLevels + lane];
-        goff = a.lanegeom[3 * kMaxLevels + lane]; gscale = a.lanegeom[4 * kMaxLevels + lane];
+        const int4 g4 = reinterpret_cast<const int4*>(a.lanegeom)[2 * lane];
+        gw = g4.x; gh = g4.y; gpitch = g4.z; goff = g4.w; gscale = a.lanegeom[8 * lane + 4];
     }
     uint32_t xyv = 0xffffffffu;                       // level 15: rejected
     if (lane < nk) xyv = a.kpxy[(size_t)b * a.capacity + i0 + lane];
@@ -1135,8 +1135,9 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
         const float rad = SA_FMUL(angle, (float)(3.14159265358979323846 / 180.0));
         sincos_f32(rad, &cav, &snv);
         slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity + i0 + lane;
-        kp->x = SA_FMUL((float)px, lscale);
-        kp->y = SA_FMUL((float)py, lscale);
+        typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+        f32x2_a4 xy = {SA_FMUL((float)px, lscale), SA_FMUL((float)py, lscale)};
+        *reinterpret_cast<f32x2_a4*>(&kp->x) = xy;     // x and y are the record's first two fields
         kp->angle = angle;
     }
     SA_DSTAMP(4);      // pass 2 done

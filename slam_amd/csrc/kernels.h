@@ -65,7 +65,7 @@ struct DescribeArgs {
     const FrameSelect* sel;
     slam_amd_keypoint* kp;
     const uint32_t* kpxy;
-    const int32_t* lanegeom;   // [5][kMaxLevels]: width, height, pitch, offset, scale bits of every level (device memory)
+    const int32_t* lanegeom;   // [kMaxLevels][8]: width, height, pitch, offset, scale bits, 0, 0, 0 of every level (device memory)
     uint8_t* desc;       // [batch][capacity][32]
     int capacity;
     int batch;
