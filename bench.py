@@ -244,54 +244,72 @@ def run_frames(args):
     frames = np.stack([seq[i % n_distinct] for i in range(B)])
     d_img = torch.from_numpy(frames).to(dev)
     KP, DM = 28, 16
-    d_kp = torch.zeros((B + 1) * CAP * KP, dtype=torch.uint8, device=dev)
-    d_desc = torch.zeros((B + 1) * CAP * 32, dtype=torch.uint8, device=dev)
-    d_cnt = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    # Two sets of result arrays used in turn: a step extracts its batch into one set and matches frame b
+    # with frame b - 1 of the same set, frame 0 with the last frame of the step before, which lies in
+    # the other set (slam_amd_frame_match_chain_async) -- no record is copied between steps.
+    sets = [{"kp": torch.zeros(B * CAP * KP, dtype=torch.uint8, device=dev),
+             "desc": torch.zeros(B * CAP * 32, dtype=torch.uint8, device=dev),
+             "cnt": torch.zeros(B, dtype=torch.int32, device=dev)} for _ in range(2)]
     d_out = torch.zeros(B * CAP * DM, dtype=torch.uint8, device=dev)
     d_nout = torch.zeros(B, dtype=torch.int32, device=dev)
-    cur = {"stream": torch.cuda.current_stream().cuda_stream}
-    kp_p, desc_p, cnt_p = d_kp.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr()
+    cur = {"stream": torch.cuda.current_stream().cuda_stream, "parity": 0}
 
-    def make_step(matcher, batch):
-        def step():
+    class Step:
+        """One step; successive calls alternate between the two sets, eager or as a pair of HIP graphs."""
+
+        def __init__(self, matcher, batch):
+            self.matcher, self.batch, self.graphs = matcher, batch, None
+
+        def launch(self, parity):
             st = cur["stream"]
-            ex.extract_batch_async(d_img, batch, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, st)
-            matcher.frame_match_batch_async(batch, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
-                                            cnt_p + 4, d_out, d_nout, max_dist=300.0, area=-1.0, max_level=-1, stream=st)
-            if batch == B:
-                # the last frame of this batch is the "previous frame" of the next one
-                d_kp[:CAP * KP].copy_(d_kp[B * CAP * KP:(B + 1) * CAP * KP], non_blocking=True)
-                d_desc[:CAP * 32].copy_(d_desc[B * CAP * 32:(B + 1) * CAP * 32], non_blocking=True)
-                d_cnt[:1].copy_(d_cnt[B:B + 1], non_blocking=True)
-        return step
+            c, p = sets[parity], sets[1 - parity]
+            last = self.batch - 1       # where a step of this batch size leaves its last frame
+            ex.extract_batch_async(d_img, self.batch, H * W, W, c["kp"].data_ptr(), c["desc"].data_ptr(),
+                                   c["cnt"].data_ptr(), CAP, st)
+            self.matcher.frame_match_chain_async(self.batch, p["desc"].data_ptr() + last * CAP * 32,
+                                                 p["kp"].data_ptr() + last * CAP * KP, p["cnt"].data_ptr() + 4 * last,
+                                                 c["desc"].data_ptr(), c["kp"].data_ptr(), CAP, c["cnt"].data_ptr(),
+                                                 d_out, d_nout, max_dist=300.0, area=-1.0, max_level=-1, stream=st)
 
-    step = make_step(m, B)
-    one_frame = make_step(m, 1)
-    step_ratio = make_step(m_ratio, B)
+        def __call__(self):
+            self.launch(cur["parity"])
+            cur["parity"] ^= 1
+
+        def replay(self):
+            self.graphs[cur["parity"]].replay()
+            cur["parity"] ^= 1
+
+    step = Step(m, B)
+    one_frame = Step(m, 1)
+    step_ratio = Step(m_ratio, B)
 
     def capture(fn):
-        """fn's launches as a HIP graph (None if capture is not possible)."""
+        """fn's launches as HIP graphs, one per set (None if capture is not possible)."""
         try:
-            torch.cuda.synchronize()
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                cur["stream"] = side.cuda_stream
-                fn()                        # warm-up on the capture stream
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
-                cur["stream"] = side.cuda_stream
-                fn()
-            return g
+            graphs = []
+            for parity in (0, 1):
+                torch.cuda.synchronize()
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    cur["stream"] = side.cuda_stream
+                    fn.launch(parity)           # warm-up on the capture stream
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    cur["stream"] = side.cuda_stream
+                    fn.launch(parity)
+                graphs.append(g)
+            fn.graphs = graphs
+            return fn
         except Exception as e:  # capture unsupported: the eager timing is reported
             sys.stderr.write("graph capture failed (%s); timing eager launches\n" % e)
             return None
         finally:
             cur["stream"] = torch.cuda.current_stream().cuda_stream
 
-    step()  # fills slot 0
+    step()  # the other set holds a frame before the first timed step
     for _ in range(args.warmup):
         step()
     for _ in range(3):
@@ -319,7 +337,7 @@ def run_frames(args):
         timed()
     times = timed_repeats(ranks, timed, args.steps, args.repeats)
     dt = statistics.median(times)
-    counts = d_cnt[1:].cpu().numpy()
+    counts = sets[cur["parity"] ^ 1]["cnt"].cpu().numpy()
     nmatch = d_nout.cpu().numpy()
     frames_per_s = world * B * args.steps / dt
 
@@ -418,7 +436,6 @@ def run_frames(args):
         extra["ratio_test_0.8"] = {"frames_per_s": round(world * B * args.steps / tr, 2),
                                    "ms_per_step": round(tr / args.steps * 1e3, 4),
                                    "matches_per_frame": round(float(d_nout.cpu().numpy().mean()), 1)}
-        step()  # slot 0 back to a plain step's state
         # ---- frames arriving in pinned host memory: H2D, compute and D2H overlapped ----
         extra["host_pipelined"] = run_host_pipelined(args, torch, ranks, ex, m, frames, dev, world)
 
@@ -477,9 +494,9 @@ def run_host_pipelined(args, torch, ranks, ex, m, frames, dev, world):
     u8 = torch.uint8
     h_img = [torch.from_numpy(frames.copy()).pin_memory() for _ in range(2)]
     d_img = [torch.empty((B, H, W), dtype=u8, device=dev) for _ in range(2)]
-    d_kp = [torch.zeros((B + 1) * CAP * KP, dtype=u8, device=dev) for _ in range(2)]
-    d_desc = [torch.zeros((B + 1) * CAP * 32, dtype=u8, device=dev) for _ in range(2)]
-    d_cnt = [torch.zeros(B + 1, dtype=torch.int32, device=dev) for _ in range(2)]
+    d_kp = [torch.zeros(B * CAP * KP, dtype=u8, device=dev) for _ in range(2)]
+    d_desc = [torch.zeros(B * CAP * 32, dtype=u8, device=dev) for _ in range(2)]
+    d_cnt = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
     d_out = [torch.zeros(B * CAP * DM, dtype=u8, device=dev) for _ in range(2)]
     d_nout = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
     h_kp = [torch.empty(B * CAP * KP, dtype=u8).pin_memory() for _ in range(2)]
@@ -505,22 +522,19 @@ def run_host_pipelined(args, torch, ranks, ex, m, frames, dev, world):
             s_comp.wait_event(ev_in[s])
             if i >= 2:
                 s_comp.wait_event(ev_out[s])        # the slot's results of batch i-2 have left
-            if i >= 1:
-                # previous frame of this batch = last frame of the batch before (other slot)
-                d_kp[s][:CAP * KP].copy_(d_kp[p][B * CAP * KP:], non_blocking=True)
-                d_desc[s][:CAP * 32].copy_(d_desc[p][B * CAP * 32:], non_blocking=True)
-                d_cnt[s][:1].copy_(d_cnt[p][B:], non_blocking=True)
             st = s_comp.cuda_stream
             kp_p, desc_p, cnt_p = d_kp[s].data_ptr(), d_desc[s].data_ptr(), d_cnt[s].data_ptr()
-            ex.extract_batch_async(d_img[s], B, H * W, W, kp_p + CAP * KP, desc_p + CAP * 32, cnt_p + 4, CAP, st)
-            m.frame_match_batch_async(B, desc_p, kp_p, CAP, cnt_p, desc_p + CAP * 32, kp_p + CAP * KP, CAP,
-                                      cnt_p + 4, d_out[s], d_nout[s], max_dist=300.0, area=-1.0, max_level=-1, stream=st)
+            ex.extract_batch_async(d_img[s], B, H * W, W, kp_p, desc_p, cnt_p, CAP, st)
+            # previous frame of this batch = last frame of the batch before (other slot)
+            m.frame_match_chain_async(B, d_desc[p].data_ptr() + (B - 1) * CAP * 32, d_kp[p].data_ptr() + (B - 1) * CAP * KP,
+                                      d_cnt[p].data_ptr() + 4 * (B - 1), desc_p, kp_p, CAP, cnt_p, d_out[s], d_nout[s],
+                                      max_dist=300.0, area=-1.0, max_level=-1, stream=st)
             ev_done[s].record(s_comp)
         with torch.cuda.stream(s_back):
             s_back.wait_event(ev_done[s])
-            h_cnt[s].copy_(d_cnt[s][1:], non_blocking=True)
-            h_kp[s].copy_(d_kp[s][CAP * KP:], non_blocking=True)
-            h_desc[s].copy_(d_desc[s][CAP * 32:], non_blocking=True)
+            h_cnt[s].copy_(d_cnt[s], non_blocking=True)
+            h_kp[s].copy_(d_kp[s], non_blocking=True)
+            h_desc[s].copy_(d_desc[s], non_blocking=True)
             h_nout[s].copy_(d_nout[s], non_blocking=True)
             h_out[s].copy_(d_out[s], non_blocking=True)
             ev_out[s].record(s_back)

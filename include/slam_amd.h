@@ -274,6 +274,22 @@ int slam_amd_frame_match_batch_async(slam_amd_matcher* m, int batch,
                                      float max_dist, float area, int max_level,
                                      slam_amd_dmatch* d_out, int32_t* d_n_out, void* stream);
 
+/* The same for a run of consecutive frames without a copy of their records: frame b of the
+ * batch (rows [b*cap, b*cap+n[b]) of d_desc / d_kp) is set 2 of problem b, and set 1 of problem
+ * b is the frame before it -- frame b-1 of the same arrays, and for b = 0 the single frame at
+ * d_prev_* (the last frame of the batch before; d_prev_n points to its count).  This is the
+ * reference's frame-against-the-one-before matching (Matcher::frameMatch(initial, current),
+ * src/tracking/mapper.cpp:34; last key frame against the current frame, src/tracking/tracker.cpp:74)
+ * over a batch of consecutive frames.  The window gate runs as a full sweep here.  Results as
+ * slam_amd_frame_match_batch_async: d_out[b*cap + i], d_n_out[b]. */
+int slam_amd_frame_match_chain_async(slam_amd_matcher* m, int batch,
+                                     const uint8_t* d_prev_desc, const slam_amd_keypoint* d_prev_kp,
+                                     const int32_t* d_prev_n,
+                                     const uint8_t* d_desc, const slam_amd_keypoint* d_kp,
+                                     int cap, const int32_t* d_n,
+                                     float max_dist, float area, int max_level,
+                                     slam_amd_dmatch* d_out, int32_t* d_n_out, void* stream);
+
 /* Keyframe-pair batch: n_keyframes descriptor sets of n_per rows each, resident
  * on the device ([n_keyframes][n_per][32]; d_kp [n_keyframes][n_per] may be null
  * when both gates are off).  d_pairs: n_pairs (query keyframe, train keyframe)

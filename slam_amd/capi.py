@@ -35,6 +35,7 @@ EXPORTS = [
     "slam_amd_matcher_debug_set_ungated_mode",
     "slam_amd_frame_match", "slam_amd_frame_match_async", "slam_amd_frame_match_noalloc_async",
     "slam_amd_frame_match_batch_async",
+    "slam_amd_frame_match_chain_async",
     "slam_amd_match_pairs_async",
     "slam_amd_project_points", "slam_amd_project_points_async", "slam_amd_duplicate_pairs",
     "slam_amd_outlier_flags",
@@ -97,6 +98,9 @@ def lib():
         l.slam_amd_frame_match_batch_async.argtypes = [
             C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
             C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.slam_amd_frame_match_chain_async.argtypes = [
+            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+            C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         l.slam_amd_match_pairs_async.argtypes = [
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
             C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
@@ -486,6 +490,14 @@ class Matcher:
                                                       _ptr(d_n1), _ptr(d_desc2), _ptr(d_kp2), cap2,
                                                       _ptr(d_n2), max_dist, area, int(max_level),
                                                       _ptr(d_out), _ptr(d_n_out), C.c_void_p(stream)))
+
+    def frame_match_chain_async(self, batch, d_prev_desc, d_prev_kp, d_prev_n, d_desc, d_kp, cap, d_n,
+                                d_out, d_n_out, max_dist=300.0, area=-1.0, max_level=4, stream=0):
+        """Frame b of the batch against the frame before it (frame 0 against the one at d_prev_*)."""
+        check(lib().slam_amd_frame_match_chain_async(self._h, batch, _ptr(d_prev_desc), _ptr(d_prev_kp),
+                                                      _ptr(d_prev_n), _ptr(d_desc), _ptr(d_kp), cap, _ptr(d_n),
+                                                      max_dist, area, int(max_level), _ptr(d_out), _ptr(d_n_out),
+                                                      C.c_void_p(stream)))
 
     def match_pairs_async(self, d_desc, d_kp, n_keyframes, n_per, d_pairs, n_pairs, d_out,
                           max_dist=300.0, area=-1.0, max_level=-1, stream=0):

@@ -106,6 +106,8 @@ struct slam_amd_extractor {
     DevBuf tiledesc;                   // level and tile coordinates of every FAST tile of a frame
     DevBuf lanegeom;                   // level geometry as a table in device memory: one level per lane of the describe kernel
     int select_keycap = 4096;          // kept survivors of a level ranked from LDS (debug knob)
+    bool hist_clean = false;           // the score histograms are all zero: the describe kernel zeroes them after the selection
+                                       // has read them; a call that fails before that leaves this false
     // host-call staging
     DevBuf h_img, h_kp, h_desc, h_count;
     int h_img_pitch = 0;
@@ -502,11 +504,11 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
                         (batch == 1 || frame_pitch % 4 == 0);
     ex->last_img0 = d_images; ex->last_frame_pitch = frame_pitch; ex->last_row_stride = row_stride;
 
-    {
+    if (!ex->hist_clean) {
         ProfScope ps(kStageMemset, st);
-        const size_t bytes = (size_t)batch * (size_t)g.nlevels * 256 * sizeof(unsigned);
-        SA_HIP(hipMemsetAsync(ex->hist.p, 0, (bytes + 255) & ~(size_t)255, st));
+        SA_HIP(hipMemsetAsync(ex->hist.p, 0, ex->hist.cap, st));
     }
+    ex->hist_clean = false;     // until this call's describe kernel is in the stream
     int rc;
     prof_mark(kStageResize, true, st);
     for (const slam_amd_extractor::PyrGroupPlan& pg : ex->pyr_groups) {
@@ -536,7 +538,9 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     da.img0 = d_images; da.img0_frame_pitch = frame_pitch; da.img0_pitch = row_stride;
     da.img0_aligned = aligned; da.pyr = ex->pyr.as<uint8_t>(); da.blur = ex->blur.as<uint8_t>(); da.sel = ex->sel.as<FrameSelect>(); da.kp = d_kp;
     da.kpxy = ex->kpxy.as<uint32_t>(); da.lanegeom = ex->lanegeom.as<int32_t>(); da.desc = d_desc; da.capacity = capacity; da.batch = batch; da.g = g;
+    da.hist_reset = ex->hist.as<unsigned>();
     { ProfScope ps(kStageDescribe, st); if ((rc = launch_describe(da, batch, st))) return rc; }
+    ex->hist_clean = true;
     return SLAM_AMD_OK;
 }
 
@@ -671,6 +675,8 @@ struct slam_amd_matcher {
     DevBuf part;                       // per-split (best, second) keys when the ratio test is on
     DevBuf sorted;                     // both sets in grid-cell order for windowed matching
     bool baked = false;                // an _async call ran under stream capture: scratch pointers live in a graph
+    bool best_clean = false;           // every key of `best` is "no match": the finalize kernel puts back what it reads, a call that
+                                       // fails half way leaves this false and the next one fills the whole buffer
     unsigned char* static_scratch = nullptr;  // this device's copy of the file-scope scratch array (no-alloc entry point)
     int window_mode = 0;               // 0: choose by size, 1: always the full sweep, 2: always cell-sorted
     int ungated_mode = 0;              // 0: matrix-core kernel when no gate and no ratio test is on, 1: always the VALU kernel
@@ -741,6 +747,7 @@ static int grow_scratch(slam_amd_matcher* m, DevBuf& b, size_t bytes, bool captu
     if (capturing || m->baked)
         SA_FAIL(SLAM_AMD_ERR_CAPACITY, "matcher scratch too small and a captured graph holds (or is recording) its "
                                        "address: call slam_amd_matcher_reserve with the largest sizes before capturing");
+    if (&b == &m->best) m->best_clean = false;      // fresh memory
     return b.reserve(bytes);
 }
 
@@ -812,7 +819,8 @@ static int match_common(slam_amd_matcher* m, int batch,
                         const uint8_t* d2, const slam_amd_keypoint* k2, int n2, const int32_t* d_n2, int cap2,
                         const int32_t* ids, int n_ids, const float* q_xy,
                         float max_dist, float area, int max_level,
-                        slam_amd_dmatch* d_out, int32_t* d_n_out, hipStream_t st, bool no_alloc = false) {
+                        slam_amd_dmatch* d_out, int32_t* d_n_out, hipStream_t st, bool no_alloc = false,
+                        bool chain = false) {
     if (!m || !d_out || !d_n_out) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
     if (n1 < 0 || n2 < 0 || n_ids < 0 || batch <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "negative size");
     if (n2 >= (1 << 20)) SA_FAIL(SLAM_AMD_ERR_ARG, "train set larger than 2^20 - 1 rows");
@@ -832,7 +840,7 @@ static int match_common(slam_amd_matcher* m, int batch,
     // With the window gate on and sets large enough to repay the reordering, both sets
     // are sorted by grid cell and only nearby tiles are compared; same result.
     bool windowed = area > 0.f && area <= 3.0e38f && nq > 0 && n2 > 0;
-    if (m->window_mode == 1 || no_alloc) windowed = false;   // the full sweep needs no reordered copies
+    if (m->window_mode == 1 || no_alloc || chain) windowed = false;   // the full sweep needs no reordered copies
     else if (m->window_mode == 0) windowed = windowed && (long long)nq * n2 >= (1LL << 25);
     // both gates off: distances on the matrix cores (second-best keys included)
     const bool use_mfma = !gated && m->ungated_mode == 0;
@@ -855,9 +863,18 @@ static int match_common(slam_amd_matcher* m, int batch,
         best_p = m->best.as<unsigned>();
         part_p = m->part.as<uint2>();
     }
-    {
-        // every (query, split) cell of the planes is written by the kernel only where the split
-        // holds train rows, and the single-plane keys are merged by atomicMin: both start as "no match"
+    // every (query, split) cell of the planes is written by the kernel only where the split
+    // holds train rows, and the single-plane keys are merged by atomicMin: both start as "no match".
+    // The matcher's own single plane is kept in that state by the finalize kernel, which puts back
+    // every key it reads; it is filled whole after it was allocated or a call did not get that far.
+    const bool self_clean = !no_alloc && !second;
+    if (self_clean) {
+        if (!m->best_clean) {
+            ProfScope ps(kStageMemset, st);
+            SA_HIP(hipMemsetAsync(m->best.p, 0xff, m->best.cap, st));
+        }
+        m->best_clean = false;      // until this call's finalize kernel is in the stream
+    } else {
         const size_t bytes = second ? fill_bytes(rows * plan.splits * sizeof(uint2)) : fill_bytes(rows * sizeof(unsigned));
         ProfScope ps(kStageMemset, st);
         SA_HIP(hipMemsetAsync(second ? static_cast<void*>(part_p) : static_cast<void*>(best_p), 0xff, bytes, st));
@@ -903,6 +920,7 @@ static int match_common(slam_amd_matcher* m, int batch,
         a.best = best_p;
         a.part = second ? part_p : nullptr;
         a.part_pitch = rows;
+        a.chain = chain ? 1 : 0;
         ProfScope ps(kStageMatch, st);
         rc = use_mfma ? launch_match_mfma(a, plan, batch, st) : launch_match(a, plan, batch, st);
         if (rc) return rc;
@@ -913,9 +931,13 @@ static int match_common(slam_amd_matcher* m, int batch,
     f.cap1 = cap1; f.dmax = dmax; f.out = d_out; f.n_out = d_n_out;
     f.part = second ? part_p : nullptr; f.part_pitch = rows; f.splits = plan.splits;
     f.ratio = m->ratio; f.histo_length = m->histo_length; f.qkp = k1; f.tkp = k2; f.cap2 = cap2;
+    f.chain = chain ? 1 : 0; f.d_n2 = d_n2;
+    f.reset = self_clean ? best_p : nullptr;
     if (capturing) m->baked = true;
     ProfScope ps(kStageFinalize, st);
-    return launch_finalize(f, batch, st);
+    rc = launch_finalize(f, batch, st);
+    if (rc == SLAM_AMD_OK && self_clean) m->best_clean = true;
+    return rc;
 }
 
 extern "C" int slam_amd_frame_match_async(slam_amd_matcher* m,
@@ -958,6 +980,20 @@ extern "C" int slam_amd_frame_match_batch_async(slam_amd_matcher* m, int batch,
     return match_common(m, batch, d_desc1, d_kp1, cap1, d_n1, cap1, d_desc2, d_kp2, cap2, d_n2, cap2,
                         nullptr, 0, nullptr, max_dist, area, max_level, d_out, d_n_out,
                         reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int slam_amd_frame_match_chain_async(slam_amd_matcher* m, int batch,
+                                                const uint8_t* d_prev_desc, const slam_amd_keypoint* d_prev_kp,
+                                                const int32_t* d_prev_n,
+                                                const uint8_t* d_desc, const slam_amd_keypoint* d_kp,
+                                                int cap, const int32_t* d_n,
+                                                float max_dist, float area, int max_level,
+                                                slam_amd_dmatch* d_out, int32_t* d_n_out, void* stream) {
+    if (cap <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "capacity must be positive");
+    if (!d_prev_n || !d_n) SA_FAIL(SLAM_AMD_ERR_ARG, "chained matching needs device counts");
+    return match_common(m, batch, d_prev_desc, d_prev_kp, cap, d_prev_n, cap, d_desc, d_kp, cap, d_n, cap,
+                        nullptr, 0, nullptr, max_dist, area, max_level, d_out, d_n_out,
+                        reinterpret_cast<hipStream_t>(stream), false, true);
 }
 
 static int upload(DevBuf& b, const void* src, size_t bytes, hipStream_t st) {

@@ -1044,10 +1044,16 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
     SA_DSTAMP(0);
     const int b = blockIdx.x % a.batch;
     const int i0 = (blockIdx.x / a.batch) * kDescKps;
+    const int lane = threadIdx.x;
+    // The first workgroup of every frame leaves the frame's score histograms zeroed for the next call
+    // (the selection kernels, which read them, ran before this one).
+    if (a.hist_reset && blockIdx.x < (unsigned)a.batch) {
+        uint4* hz = reinterpret_cast<uint4*>(a.hist_reset + (size_t)b * a.g.nlevels * 256);
+        for (int i = lane; i < a.g.nlevels * 64; i += 64) hz[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     const int n = min(a.sel[b].total, a.capacity);
     if (i0 >= n) return;
     const int nk = min(kDescKps, n - i0);
-    const int lane = threadIdx.x;
     SA_DSTAMP(1);      // count known
     auto exchange = [](int from_lane, int v) { return __builtin_amdgcn_ds_bpermute(4 * from_lane, v); };
 

@@ -67,6 +67,7 @@ struct DescribeArgs {
     const uint32_t* kpxy;
     const int32_t* lanegeom;   // [kMaxLevels][8]: width, height, pitch, offset, scale bits, 0, 0, 0 of every level (device memory)
     uint8_t* desc;       // [batch][capacity][32]
+    unsigned* hist_reset; // if set: the score histograms [batch][nlevels][256]; the selection has read them, this kernel zeroes them for the next call
     int capacity;
     int batch;
     PyrGeom g;
@@ -99,7 +100,32 @@ struct MatchArgs {
     // second-best mode (ratio test): every split stores (best key, second key)
     uint2* part;                     // [splits][part_pitch], or null
     size_t part_pitch;               // rows per split plane (batch * cap1)
+    int chain;                       // 1: every frame of set 2 against the frame before it (see query_side)
 };
+
+// Query side of problem `prob`.  Plain batches: rows prob * cap1 ... of the set-1 arrays.  Chained
+// batches (every frame against the one before it): problem 0 takes the set-1 arrays, which hold one
+// frame, the one before the batch; problem p >= 1 takes frame p - 1 of the set-2 arrays.  Results are
+// indexed by prob * cap1 either way.
+struct QuerySide {
+    const uint8_t* desc;
+    const slam_amd_keypoint* kp;
+    size_t base;              // first row of the problem's queries in desc / kp
+    const int32_t* count;     // device count of the problem's queries, or null
+};
+__device__ __forceinline__ QuerySide query_side(int chain, int prob, const uint8_t* qdesc, const slam_amd_keypoint* qkp,
+                                                const int32_t* d_n1, int cap1, const uint8_t* tdesc,
+                                                const slam_amd_keypoint* tkp, const int32_t* d_n2, int cap2) {
+    QuerySide q;
+    if (!chain) {
+        q.desc = qdesc; q.kp = qkp; q.base = (size_t)prob * cap1; q.count = d_n1 ? d_n1 + prob : nullptr;
+    } else if (prob == 0) {
+        q.desc = qdesc; q.kp = qkp; q.base = 0; q.count = d_n1;
+    } else {
+        q.desc = tdesc; q.kp = tkp; q.base = (size_t)(prob - 1) * cap2; q.count = d_n2 ? d_n2 + (prob - 1) : nullptr;
+    }
+    return q;
+}
 
 constexpr int kMaxSecondSplits = 16;
 
@@ -164,6 +190,9 @@ struct FinalizeArgs {
     const slam_amd_keypoint* qkp;
     const slam_amd_keypoint* tkp;
     int cap2;
+    int chain;                // as in MatchArgs
+    const int32_t* d_n2;      // chained batches: the counts of set 2 are the query counts of the next problem
+    unsigned* reset;          // if set (= best): every key read is put back to "no match", so the next call needs no fill
 };
 
 struct ProjectArgs {

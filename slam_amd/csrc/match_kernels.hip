@@ -52,11 +52,13 @@ __global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
     int prob, qblock, split;
     size_t qbase, tbase;  // first row of the problem's query / train set
     int nq, nt;
+    QuerySide qs = {a.qdesc, a.qkp, 0, nullptr};      // where the queries are read (qbase: where results go)
     if (PAIRS) {
         prob = blockIdx.x / a.qblocks;
         qblock = blockIdx.x - prob * a.qblocks;
         split = 0;
         qbase = (size_t)a.pairs[2 * prob] * a.n_per;
+        qs.base = qbase;
         tbase = (size_t)a.pairs[2 * prob + 1] * a.n_per;
         nq = nt = a.n_per;
     } else {
@@ -70,8 +72,9 @@ __global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
         qblock = rest / a.splits;
         qbase = (size_t)prob * a.cap1;
         tbase = (size_t)prob * a.cap2;
+        qs = query_side(a.chain, prob, a.qdesc, a.qkp, a.d_n1, a.cap1, a.tdesc, a.tkp, a.d_n2, a.cap2);
         int n1 = a.n1, n2 = a.n2;
-        if (a.d_n1) n1 = min(n1, a.d_n1[prob]);
+        if (qs.count) n1 = min(n1, *qs.count);
         if (a.d_n2) n2 = min(n2, a.d_n2[prob]);
         nq = a.ids ? a.n_ids : n1;
         nt = n2;
@@ -92,8 +95,8 @@ __global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
         qx[k] = qy[k] = 0.f;
         qhigh[k] = false;
         if (qi < nq) {
-            const size_t row = qbase + (size_t)((!PAIRS && a.ids) ? a.ids[qi] : qi);
-            const uint4* p = reinterpret_cast<const uint4*>(a.qdesc + row * 32);
+            const size_t row = qs.base + (size_t)((!PAIRS && a.ids) ? a.ids[qi] : qi);
+            const uint4* p = reinterpret_cast<const uint4*>(qs.desc + row * 32);
             const uint4 lo = p[0], hi = p[1];
             q[k][0] = lo.x; q[k][1] = lo.y; q[k][2] = lo.z; q[k][3] = lo.w;
             q[k][4] = hi.x; q[k][5] = hi.y; q[k][6] = hi.z; q[k][7] = hi.w;
@@ -102,11 +105,11 @@ __global__ __launch_bounds__(kMatchBlock) void match_kernel(MatchArgs a) {
                     qx[k] = a.q_xy[2 * (qbase + qi)];
                     qy[k] = a.q_xy[2 * (qbase + qi) + 1];
                 } else {
-                    qx[k] = a.qkp[row].x;
-                    qy[k] = a.qkp[row].y;
+                    qx[k] = qs.kp[row].x;
+                    qy[k] = qs.kp[row].y;
                 }
             }
-            if (LEVEL) qhigh[k] = a.qkp[row].octave > a.max_level;
+            if (LEVEL) qhigh[k] = qs.kp[row].octave > a.max_level;
         } else {
 #pragma unroll
             for (int w = 0; w < 8; w++) q[k][w] = 0;
@@ -206,8 +209,9 @@ __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) 
     __shared__ int s_wave[16];
     __shared__ int s_hist[EX ? 64 : 1];
     const int prob = blockIdx.x;
+    const QuerySide qs = query_side(a.chain, prob, nullptr, a.qkp, a.d_n1, a.cap1, nullptr, a.tkp, a.d_n2, a.cap2);
     int n1 = a.n1;
-    if (a.d_n1) n1 = min(n1, a.d_n1[prob]);
+    if (qs.count) n1 = min(n1, *qs.count);
     const int nq = a.ids ? a.n_ids : n1;
     const unsigned* best = a.best + (size_t)prob * a.cap1;
     slam_amd_dmatch* out = a.out + (size_t)prob * a.cap1;
@@ -234,9 +238,9 @@ __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) 
         return b;
     };
     auto bin_of = [&](int q, unsigned key) -> int {
-        const size_t qrow = (size_t)prob * a.cap1 + (a.ids ? a.ids[q] : q);
+        const size_t qrow = qs.base + (a.ids ? a.ids[q] : q);
         const size_t trow = (size_t)prob * a.cap2 + (key & ((1u << kIdxBits) - 1));
-        return rotation_bin(a.qkp[qrow].angle, a.tkp[trow].angle, a.histo_length);
+        return rotation_bin(qs.kp[qrow].angle, a.tkp[trow].angle, a.histo_length);
     };
     int i1 = -1, i2 = -1, i3 = -1;
     if (rot_on) {
@@ -281,6 +285,8 @@ __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) 
         for (int k = 0; k < kFinalRows; k++) {
             const int q = base + (wave * kFinalRows + k) * 64 + lane;
             key[k] = q < nq ? kept(q) : kNoMatch;
+            // (the last read of this query's running key: the matching kernels touch exactly the rows below nq)
+            if (a.reset && q < nq) a.reset[(size_t)prob * a.cap1 + q] = kNoMatch;
             mask[k] = __ballot(key[k] != kNoMatch);
             wcount += __popcll(mask[k]);
         }

@@ -68,11 +68,13 @@ __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
     int prob, qblock, split;
     size_t qbase, tbase;
     int nq, nt;
+    QuerySide qs = {a.qdesc, a.qkp, 0, nullptr};      // where the queries are read (qbase: where results go)
     if (PAIRS) {
         prob = blockIdx.x / a.qblocks;
         qblock = blockIdx.x - prob * a.qblocks;
         split = 0;
         qbase = (size_t)a.pairs[2 * prob] * a.n_per;
+        qs.base = qbase;
         tbase = (size_t)a.pairs[2 * prob + 1] * a.n_per;
         nq = nt = a.n_per;
     } else {
@@ -84,8 +86,9 @@ __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
         qblock = rest / a.splits;
         qbase = (size_t)prob * a.cap1;
         tbase = (size_t)prob * a.cap2;
+        qs = query_side(a.chain, prob, a.qdesc, a.qkp, a.d_n1, a.cap1, a.tdesc, a.tkp, a.d_n2, a.cap2);
         int n1 = a.n1, n2 = a.n2;
-        if (a.d_n1) n1 = min(n1, a.d_n1[prob]);
+        if (qs.count) n1 = min(n1, *qs.count);
         if (a.d_n2) n2 = min(n2, a.d_n2[prob]);
         nq = a.ids ? a.n_ids : n1;
         nt = n2;
@@ -107,8 +110,8 @@ __global__ __launch_bounds__(kMmBlock) void match_mfma_kernel(MatchArgs a) {
         qidx[b] = qi;
         uint4 q = make_uint4(0u, 0u, 0u, 0u);
         if (qi < nq) {
-            const size_t row = qbase + (size_t)((!PAIRS && a.ids) ? a.ids[qi] : qi);
-            q = reinterpret_cast<const uint4*>(a.qdesc + row * 32)[h];
+            const size_t row = qs.base + (size_t)((!PAIRS && a.ids) ? a.ids[qi] : qi);
+            q = reinterpret_cast<const uint4*>(qs.desc + row * 32)[h];
         }
         const unsigned w[4] = {q.x, q.y, q.z, q.w};
         int pc = 0;

@@ -222,6 +222,48 @@ def test_projection_windowed_match_20k_vs_4k(oracle, capi):
     assert full.tobytes() == ref.tobytes()
 
 
+def test_frame_match_chain(oracle, capi):
+    """Every frame of a batch against the one before it, frame 0 against a frame held elsewhere: the
+    chained call against the oracle's match of each consecutive pair (matrix-core path, gated popcount
+    path, and the ratio / rotation options)."""
+    torch = _torch()
+    st = torch.cuda.current_stream().cuda_stream
+    B, CAP = 5, 384
+    counts = [300, 384, 0, 77, 201]
+    n_prev = 250
+    sets = [_sets(CAP, CAP, 90 + b) for b in range(B + 1)]
+    d_all = np.concatenate([sets[b][0] for b in range(B)]); k_all = np.concatenate([sets[b][1] for b in range(B)])
+    D = torch.from_numpy(d_all).cuda(); K = _dev_kp(torch, k_all)
+    Dp = torch.from_numpy(sets[B][0]).cuda(); Kp = _dev_kp(torch, sets[B][1])
+    N = torch.tensor(counts, dtype=torch.int32, device="cuda"); Np = torch.tensor([n_prev], dtype=torch.int32, device="cuda")
+    out = torch.zeros(B * CAP * DM, dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(B, dtype=torch.int32, device="cuda")
+    m = capi.Matcher()
+    m.reserve(B, CAP, CAP)
+
+    def sides(b):
+        if b == 0:
+            return sets[B][0][:n_prev], sets[B][1][:n_prev]
+        return sets[b - 1][0][:counts[b - 1]], sets[b - 1][1][:counts[b - 1]]
+
+    for ratio, histo in ((0.0, 0), (0.9, 30)):
+        m.set_options(ratio, histo)
+        m.reserve(B, CAP, CAP)
+        for area, lvl in ((-1.0, -1), (80.0, 4), (25.0, -1)):
+            m.frame_match_chain_async(B, Dp, Kp, Np, D, K, CAP, N, out, nout, 300.0, area, lvl, st)
+            torch.cuda.synchronize()
+            res = out.cpu().numpy().view(capi.DMATCH_DTYPE)
+            for b in range(B):
+                d1, k1 = sides(b)
+                d2, k2 = sets[b][0][:counts[b]], sets[b][1][:counts[b]]
+                if ratio > 0:
+                    ref = oracle.match_gated_ex(d1, k1, d2, k2, 300.0, area, lvl, ratio, histo)
+                else:
+                    ref = oracle.match_gated(d1, k1, d2, k2, 300.0, area, lvl)
+                assert int(nout[b].item()) == len(ref), (b, area, ratio)
+                assert res[b * CAP: b * CAP + len(ref)].tobytes() == ref.tobytes(), (b, area, ratio)
+
+
 def test_frame_match_async_and_batch(oracle, capi):
     torch = _torch()
     st = torch.cuda.current_stream().cuda_stream
