@@ -27,8 +27,16 @@ __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
 // floor(x / d) for 0 <= x < 256, 1 <= d < 256, by one multiplication.
 __device__ __forceinline__ int small_div(int x, int d_inv16) { return (x * d_inv16) >> 16; }
 
+#ifndef SA_PYR_STAMPS
+#define SA_PYR_STAMPS 0   // 1: prints the clock at the kernel's step boundaries for a few workgroups (timing experiments)
+#endif
 __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
     extern __shared__ __align__(16) uint8_t py_lds[];
+#if SA_PYR_STAMPS
+    unsigned long long pst[12] = {};
+    int psn = 0;
+    pst[psn++] = __builtin_amdgcn_s_memtime();
+#endif
     const int slots = a.last - a.first + 2;          // slot 0 = source level (first - 1), slot k = level first + k - 1
     const int ntiles = a.ntx * a.nty;
     const int b = blockIdx.x / ntiles, tile = blockIdx.x - b * ntiles;
@@ -45,7 +53,10 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
     //      they are only ever read with weight 0.  All loads of a thread are issued first (up to
     //      kStage dwords per trip; a 32-pixel tile needs one trip), the coefficient slices are
     //      fetched while they are in flight, then the dwords go to LDS ----
-    constexpr int kStage = 16;
+#ifndef SA_PYR_STAGE
+#define SA_PYR_STAGE 16
+#endif
+    constexpr int kStage = SA_PYR_STAGE;
     const int ls0 = a.first - 1;
     const uint8_t* src_img;
     int src_pitch, src_aligned;
@@ -113,6 +124,9 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
     __syncthreads();
 #if SA_PYR_EXP == 1
     return;
+#endif
+#if SA_PYR_STAMPS
+    pst[psn++] = __builtin_amdgcn_s_memtime();
 #endif
 
     // ---- the chain ----
@@ -195,7 +209,15 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
             }
         }
         lds_barrier();
+#if SA_PYR_STAMPS
+        pst[psn++] = __builtin_amdgcn_s_memtime();
+#endif
     }
+#if SA_PYR_STAMPS
+    if (threadIdx.x == 0 && (blockIdx.x == 100 || blockIdx.x == 900 || blockIdx.x == 1100 || blockIdx.x == 1800))
+        printf("pyramid wg %d start %llu : stage %llu levels %llu %llu %llu %llu %llu %llu %llu\n", (int)blockIdx.x, pst[0] & 0xffffffull, pst[1] - pst[0],
+               pst[2] - pst[1], pst[3] - pst[2], pst[4] - pst[3], pst[5] - pst[4], pst[6] - pst[5], pst[7] - pst[6], pst[8] - pst[7]);
+#endif
 }
 
 int launch_pyramid(const PyramidArgs& a, int batch, size_t lds_bytes, hipStream_t st) {
