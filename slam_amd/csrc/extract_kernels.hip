@@ -286,7 +286,10 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         for (int it = 0; it < 3; it++) {
             const int r = rr + 14 * it;
             const int gy = y0 - 1 + r;
-            if (r < kScRows) {      // uniform per wave except in the last one; the reads stay inside the tile
+            const bool row_ok = gy >= edge - 1 && gy < h - edge + 1;
+            // (rows that cannot hold a keypoint or a neighbour of one are skipped: in the tiles along the upper
+            // and lower border whole waves fall out; the reads stay inside the tile either way)
+            if (r < kScRows && row_ok && cmask != 0u) {     // (cmask is 0 where the level is too small for any keypoint)
                 const uint2* rowc = s_eo + (r + 3) * kEoPitch + 1 + cg;
                 const uint2 W0 = rowc[-1], C = rowc[0], W2 = rowc[1];
                 const uint2 U = s_eo[r * kEoPitch + 1 + cg], D = s_eo[(r + 6) * kEoPitch + 1 + cg];
@@ -305,8 +308,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
                                    (shift_right(dark_o, 8 - 4 * it) & (0x00020002u << (4 * it))) |
                                    (shift_right(brig_e, 7 - 4 * it) & (0x00040004u << (4 * it))) |
                                    (shift_right(brig_o, 6 - 4 * it) & (0x00080008u << (4 * it)));
-                const bool row_ok = gy >= edge - 1 && gy < h - edge + 1;
-                Y |= y & (row_ok ? cmask << (4 * it) : 0u);
+                Y |= y & (cmask << (4 * it));
             }
         }
         // one list entry per passing pixel: staged offset | darker << 12 | brighter << 14
