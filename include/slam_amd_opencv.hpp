@@ -5,7 +5,7 @@
 // src/tracking/*.cpp and main.cpp compile unchanged; src/frame/detector.cpp and
 // src/frame/matcher.cpp drop out of the build.  Needs OpenCV headers (core, features2d) and links
 // libslam_amd.so.  The two shims under include/dropin/frame/ carry the reference's file names and
-// include guards; INTEGRATION.md has the three CMake lines.
+// include guards (put include/dropin before the reference's include directory and drop detector.cpp / matcher.cpp from the sources).
 //
 // slam::Matcher needs the complete slam::KeyFrame (include "map/keyframe.hpp" first, as the
 // reference's matcher.hpp does); define SLAM_AMD_OPENCV_DETECTOR_ONLY to get slam::Detector alone.
