@@ -97,7 +97,7 @@ struct slam_amd_extractor {
     const uint32_t* xtab[kMaxLevels] = {};
     const uint32_t* ytab[kMaxLevels] = {};
     struct PyrGroupPlan {
-        int first, last, ntx, nty, tabcap, buf_even, buf_odd;
+        int first, last, ntx, nty, tab_bytes, buf_even, buf_odd;
         const PyrSpan* spanx; const PyrSpan* spany;
         size_t lds_bytes;
     };
@@ -205,7 +205,8 @@ static int build_geometry_of(const slam_amd_orb_params& p, int width, int height
 // destination index d of level l (padded by replication past the level size).
 struct AxisPlan {
     std::vector<PyrSpan> span;   // [nt][slots]
-    int max_len_even = 0, max_len_odd = 0, max_tab = 0;
+    int max_len_even = 0, max_len_odd = 0;
+    int max_tab_sum = 0;         // most coefficient entries one tile keeps for all levels of the group (x: whole dwords)
 };
 
 static AxisPlan plan_axis(const std::vector<std::vector<int32_t>>& off, const int* size, int first, int last,
@@ -217,6 +218,7 @@ static AxisPlan plan_axis(const std::vector<std::vector<int32_t>>& off, const in
     for (int i = 0; i < nt; i++) {
         PyrSpan* sp = &ap.span[(size_t)i * slots];
         int need0 = 0, need1 = 0;   // needed range of the level above (slot k + 1), exact
+        int tab_sum = 0;
         for (int k = slots - 1; k >= 0; k--) {
             const int l = first + k - 1;
             const int n = size[l];
@@ -248,8 +250,9 @@ static AxisPlan plan_axis(const std::vector<std::vector<int32_t>>& off, const in
             sp[k].c0 = (short)c0; sp[k].c1 = (short)c1; sp[k].o0 = (short)o0; sp[k].o1 = (short)o1;
             const int len = c1 - c0;
             if (k & 1) ap.max_len_odd = std::max(ap.max_len_odd, len); else ap.max_len_even = std::max(ap.max_len_even, len);
-            if (k >= 1) ap.max_tab = std::max(ap.max_tab, len);
+            if (k >= 1) tab_sum += len;
         }
+        ap.max_tab_sum = std::max(ap.max_tab_sum, tab_sum);
     }
     return ap;
 }
@@ -257,6 +260,14 @@ static AxisPlan plan_axis(const std::vector<std::vector<int32_t>>& off, const in
 // A chain buffer holds whole staged rows; the horizontal pass reads three dwords from the dword of a
 // group's first tap, up to 11 bytes past the last one it needs: 16 spare bytes.
 static size_t pyr_buffer_bytes(size_t area) { return ((area + 15) & ~(size_t)15) + 16; }
+
+// The coefficient slices of a tile lie packed in LDS: every level's x slice (whole dwords of pixels, so
+// multiples of four entries of 4 bytes), then every level's y slice (entries of 2 bytes: 9 bits of weight
+// and the source row within the staged region, which must fit 7 bits); the chain buffers that follow
+// start on 16 bytes.
+static size_t pyr_table_bytes(const AxisPlan& ax, const AxisPlan& ay) {
+    return ((size_t)ax.max_tab_sum * 4 + (size_t)ay.max_tab_sum * 2 + 15) & ~(size_t)15;
+}
 
 struct HostGroup { int first, last, T, ntx, nty; AxisPlan ax, ay; size_t lds; };
 struct HostPyramidPlan {
@@ -307,11 +318,11 @@ static int make_pyramid_plan(const PyrGeom& g, HostPyramidPlan& plan) {
         out.ntx = div_up(ws[last], T); out.nty = div_up(hs[last], T);
         out.ax = plan_axis(xo, ws, first, last, T, out.ntx, true);
         out.ay = plan_axis(yo, hs, first, last, T, out.nty, false);
-        const int tabcap = (std::max(out.ax.max_tab, out.ay.max_tab) + 3) & ~3;
         const size_t even = (size_t)out.ax.max_len_even * out.ay.max_len_even, odd = (size_t)out.ax.max_len_odd * out.ay.max_len_odd;
-        out.lds = (size_t)(last - first + 1) * tabcap * 8 + pyr_buffer_bytes(even) + pyr_buffer_bytes(odd);
+        out.lds = pyr_table_bytes(out.ax, out.ay) + pyr_buffer_bytes(even) + pyr_buffer_bytes(odd);
         const int widest = std::max(out.ax.max_len_even, out.ax.max_len_odd);
-        return out.lds <= kLdsBudget && widest <= 1020;
+        const int tallest = std::max(out.ay.max_len_even, out.ay.max_len_odd);
+        return out.lds <= kLdsBudget && widest <= 1020 && tallest <= 128;
     };
     for (int first = 1; first < g.nlevels;) {
         HostGroup best;
@@ -324,7 +335,10 @@ static int make_pyramid_plan(const PyrGeom& g, HostPyramidPlan& plan) {
             // are preferred (fewer, larger workgroups: less recomputation at the tile borders)
             int last = first;
             HostGroup cand;
-            while (last < g.nlevels && try_group(first, last, T, cand)) { best = cand; found = true; last++; }
+#ifndef SA_PYR_MAX_GROUP
+#define SA_PYR_MAX_GROUP kMaxLevels
+#endif
+            while (last < g.nlevels && last - first < SA_PYR_MAX_GROUP && try_group(first, last, T, cand)) { best = cand; found = true; last++; }
             if (found) break;
         }
         if (!found) SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "scale factor too large for the pyramid kernel");
@@ -374,7 +388,7 @@ static int build_tables(slam_amd_extractor* ex) {
         const HostGroup& hg = groups[i];
         slam_amd_extractor::PyrGroupPlan pg;
         pg.first = hg.first; pg.last = hg.last; pg.ntx = hg.ntx; pg.nty = hg.nty;
-        pg.tabcap = (std::max(hg.ax.max_tab, hg.ay.max_tab) + 3) & ~3;
+        pg.tab_bytes = (int)pyr_table_bytes(hg.ax, hg.ay);
         pg.buf_even = (int)pyr_buffer_bytes((size_t)hg.ax.max_len_even * hg.ay.max_len_even);
         pg.buf_odd = (int)pyr_buffer_bytes((size_t)hg.ax.max_len_odd * hg.ay.max_len_odd);
         pg.spanx = reinterpret_cast<const PyrSpan*>(base + o_sx[i]);
@@ -519,7 +533,7 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
         a.first = pg.first; a.last = pg.last; a.ntx = pg.ntx; a.nty = pg.nty;
         a.spanx = pg.spanx; a.spany = pg.spany;
         for (int l = 1; l < g.nlevels; l++) { a.xtab[l] = ex->xtab[l]; a.ytab[l] = ex->ytab[l]; }
-        a.tabcap = pg.tabcap; a.buf_even = pg.buf_even; a.buf_odd = pg.buf_odd;
+        a.tab_bytes = pg.tab_bytes; a.buf_even = pg.buf_even; a.buf_odd = pg.buf_odd;
         if ((rc = launch_pyramid(a, batch, pg.lds_bytes, st))) return rc;
     }
     prof_mark(kStageResize, false, st);

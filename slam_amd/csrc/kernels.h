@@ -21,7 +21,7 @@ struct PyramidArgs {
     const PyrSpan* spany;      // [nty][last - first + 2]
     const uint32_t* xtab[kMaxLevels];  // per level: source index | second-tap weight << 16, padded
     const uint32_t* ytab[kMaxLevels];
-    int tabcap;                // LDS entries reserved per coefficient slice (multiple of 4)
+    int tab_bytes;             // LDS bytes reserved for a tile's coefficient slices (multiple of 16)
     int buf_even, buf_odd;     // bytes of the LDS buffers of the even / odd slots
 };
 

@@ -30,7 +30,7 @@ __device__ __forceinline__ int small_div(int x, int d_inv16) { return (x * d_inv
 #ifndef SA_PYR_STAMPS
 #define SA_PYR_STAMPS 0   // 1: prints the clock at the kernel's step boundaries for a few workgroups (timing experiments)
 #endif
-__global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void pyramid_kernel(PyramidArgs a) {
     extern __shared__ __align__(16) uint8_t py_lds[];
 #if SA_PYR_STAMPS
     unsigned long long pst[12] = {};
@@ -43,9 +43,13 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
     const int tj = tile / a.ntx, ti = tile - tj * a.ntx;
     const PyrSpan* sx = a.spanx + ti * slots;
     const PyrSpan* sy = a.spany + tj * slots;
-    uint32_t* s_xt = reinterpret_cast<uint32_t*>(py_lds);                 // [slots - 1][tabcap]
-    uint32_t* s_yt = s_xt + (slots - 1) * a.tabcap;                       // [slots - 1][tabcap]
-    uint8_t* buf0 = reinterpret_cast<uint8_t*>(s_yt + (slots - 1) * a.tabcap);
+    // coefficient slices, packed: the x slice of every level (source column | weight << 16, multiples of
+    // four entries), then the y slices (weight | source row within the staged region << 9, 16 bits each)
+    uint32_t* s_xt = reinterpret_cast<uint32_t*>(py_lds);
+    int x_entries = 0;
+    for (int k = 1; k < slots; k++) x_entries += sx[k].c1 - sx[k].c0;
+    uint16_t* s_yt = reinterpret_cast<uint16_t*>(s_xt + x_entries);
+    uint8_t* buf0 = py_lds + a.tab_bytes;
     uint8_t* buf1 = buf0 + a.buf_even;
     const int tid = threadIdx.x;
 
@@ -99,6 +103,10 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
             if (li[u] >= 0) *reinterpret_cast<uint32_t*>(buf0 + li[u] * 4) = sv[u];
     };
     stage_loads();
+#if SA_PYR_STAMPS
+    unsigned long long sst[4] = {};
+    sst[0] = __builtin_amdgcn_s_memtime();
+#endif
     // ---- coefficient slices of every level of the group.  A slice covers the computed range,
     //      which is the needed range widened to whole dwords; the extra positions are never used,
     //      so their source indices are clamped into the source range instead of widening that too ----
@@ -106,21 +114,32 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
     for (int k = 1 + (tid >> 6); k < slots; k += 4) {
         const int l = a.first + k - 1;
         const int nx = sx[k].c1 - sx[k].c0, ny = sy[k].c1 - sy[k].c0;
+        int xat = 0, yat = 0;
+        for (int j = 1; j < k; j++) { xat += sx[j].c1 - sx[j].c0; yat += sy[j].c1 - sy[j].c0; }
         const unsigned xlo = sx[k - 1].c0, xhi = sx[k - 1].c1 - 2, ylo = sy[k - 1].c0, yhi = sy[k - 1].c1 - 2;
         for (int i = tid & 63; i < nx; i += 64) {
             const uint32_t e = a.xtab[l][sx[k].c0 + i];
-            s_xt[(k - 1) * a.tabcap + i] = (e & 0xffff0000u) | min(max(e & 0xffffu, xlo), xhi);
+            s_xt[xat + i] = (e & 0xffff0000u) | min(max(e & 0xffffu, xlo), xhi);
         }
         for (int i = tid & 63; i < ny; i += 64) {
             const uint32_t e = a.ytab[l][sy[k].c0 + i];
-            s_yt[(k - 1) * a.tabcap + i] = (e & 0xffff0000u) | min(max(e & 0xffffu, ylo), yhi);
+            s_yt[yat + i] = (uint16_t)((e >> 16) | ((min(max(e & 0xffffu, ylo), yhi) - ylo) << 9));
         }
     }
+#if SA_PYR_STAMPS
+    sst[1] = __builtin_amdgcn_s_memtime();
+#endif
     stage_stores();
+#if SA_PYR_STAMPS
+    sst[2] = __builtin_amdgcn_s_memtime();
+#endif
     while (st_row < st_rows) {     // larger source regions: further trips
         stage_loads();
         stage_stores();
     }
+#if SA_PYR_STAMPS
+    sst[3] = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
 #if SA_PYR_EXP == 1
     return;
@@ -138,19 +157,19 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
     // selector constant per thread), c0 a + c1 b as one 16-bit dot product -- exact in 16 bits.
     // Vertical step: (m0 h0 + m1 h1 + 2^15) >> 16, again one dot product per pixel, byte 2 of which
     // is the result.
+    const uint32_t* xt = s_xt;
+    const uint16_t* yt = s_yt;
     for (int k = 1; k < slots; k++) {
         const int l = a.first + k - 1;
         const LevelGeom& L = a.g.lv[l];
         const uint8_t* sbuf = (k & 1) ? buf0 : buf1;
         uint8_t* dbuf = (k & 1) ? buf1 : buf0;
         const int spitch = ((sx[k - 1].c1 - sx[k - 1].c0 + 3) >> 2) << 2;
-        const int sx0 = sx[k - 1].c0, sy0 = sy[k - 1].c0;
+        const int sx0 = sx[k - 1].c0;
         const int cx0 = sx[k].c0, cy0 = sy[k].c0;
         const int n4 = (sx[k].c1 - cx0 + 3) >> 2, rows = sy[k].c1 - cy0;
         const int ox0 = sx[k].o0, ox1 = sx[k].o1, oy0 = sy[k].o0, oy1 = sy[k].o1;
         uint8_t* gdst = a.pyr + (size_t)b * a.g.frame_bytes + L.off;
-        const uint32_t* xt = s_xt + (k - 1) * a.tabcap;
-        const uint32_t* yt = s_yt + (k - 1) * a.tabcap;
         const int inv = 65536 / n4 + 1;
         const int par = 256 / n4;                       // rows side by side
         const int rr = small_div(tid, inv), gi = tid - rr * n4;
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
                 for (int u = 0; u < kUnroll; u++) ye[u] = yt[min(r + u * par, rows - 1)];
 #pragma unroll
                 for (int u = 0; u < kUnroll; u++) {
-                    const uint32_t* p = reinterpret_cast<const uint32_t*>(src + ((ye[u] & 0xffffu) - (unsigned)sy0) * spitch);
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(src + (ye[u] >> 9) * spitch);
                     const uint32_t* q = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(p) + spitch);
                     d[u][0][0] = p[0]; d[u][0][1] = p[1]; d[u][0][2] = p[2];
                     d[u][1][0] = q[0]; d[u][1][1] = q[1]; d[u][1][2] = q[2];
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
 #pragma unroll
                         for (int j = 0; j < 4; j++) h[t][j] = dot2_u16(__builtin_amdgcn_perm(hi, lo, sel[j]), wgt[j], 0u);
                     }
-                    const unsigned m1 = ye[u] >> 16, mw = (256u - m1) | (m1 << 16);
+                    const unsigned m1 = ye[u] & 0x1ffu, mw = (256u - m1) | (m1 << 16);
                     uint32_t v[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++)
@@ -208,6 +227,8 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
                 }
             }
         }
+        xt += sx[k].c1 - cx0;
+        yt += rows;
         lds_barrier();
 #if SA_PYR_STAMPS
         pst[psn++] = __builtin_amdgcn_s_memtime();
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(256) void pyramid_kernel(PyramidArgs a) {
     }
 #if SA_PYR_STAMPS
     if (threadIdx.x == 0 && (blockIdx.x == 100 || blockIdx.x == 900 || blockIdx.x == 1100 || blockIdx.x == 1800))
-        printf("pyramid wg %d start %llu : stage %llu levels %llu %llu %llu %llu %llu %llu %llu\n", (int)blockIdx.x, pst[0] & 0xffffffull, pst[1] - pst[0],
+        printf("pyramid wg %d start %llu : loads issued %llu tables %llu stores %llu trips %llu | stage %llu levels %llu %llu %llu %llu %llu %llu %llu\n", (int)blockIdx.x, pst[0] & 0xffffffull, sst[0] - pst[0], sst[1] - sst[0], sst[2] - sst[1], sst[3] - sst[2], pst[1] - pst[0],
                pst[2] - pst[1], pst[3] - pst[2], pst[4] - pst[3], pst[5] - pst[4], pst[6] - pst[5], pst[7] - pst[6], pst[8] - pst[7]);
 #endif
 }
