@@ -97,7 +97,8 @@ struct slam_amd_extractor {
     const uint32_t* xtab[kMaxLevels] = {};
     const uint32_t* ytab[kMaxLevels] = {};
     struct PyrGroupPlan {
-        int first, last, ntx, nty, tab_bytes, buf_even, buf_odd;
+        int first, last, ntx, nty, tab_bytes, buf_even, buf_odd, x_entries;
+        short xat[kMaxLevels + 1] = {}, yat[kMaxLevels + 1] = {};
         const PyrSpan* spanx; const PyrSpan* spany;
         size_t lds_bytes;
     };
@@ -206,7 +207,7 @@ static int build_geometry_of(const slam_amd_orb_params& p, int width, int height
 struct AxisPlan {
     std::vector<PyrSpan> span;   // [nt][slots]
     int max_len_even = 0, max_len_odd = 0;
-    int max_tab_sum = 0;         // most coefficient entries one tile keeps for all levels of the group (x: whole dwords)
+    std::vector<int> max_len_slot;   // [slots]: longest computed range of any tile at that slot
 };
 
 static AxisPlan plan_axis(const std::vector<std::vector<int32_t>>& off, const int* size, int first, int last,
@@ -214,11 +215,11 @@ static AxisPlan plan_axis(const std::vector<std::vector<int32_t>>& off, const in
     const int slots = last - first + 2;
     AxisPlan ap;
     ap.span.resize((size_t)nt * slots);
+    ap.max_len_slot.assign(slots, 0);
     auto up4 = [](int v) { return (v + 3) & ~3; };
     for (int i = 0; i < nt; i++) {
         PyrSpan* sp = &ap.span[(size_t)i * slots];
         int need0 = 0, need1 = 0;   // needed range of the level above (slot k + 1), exact
-        int tab_sum = 0;
         for (int k = slots - 1; k >= 0; k--) {
             const int l = first + k - 1;
             const int n = size[l];
@@ -250,9 +251,8 @@ static AxisPlan plan_axis(const std::vector<std::vector<int32_t>>& off, const in
             sp[k].c0 = (short)c0; sp[k].c1 = (short)c1; sp[k].o0 = (short)o0; sp[k].o1 = (short)o1;
             const int len = c1 - c0;
             if (k & 1) ap.max_len_odd = std::max(ap.max_len_odd, len); else ap.max_len_even = std::max(ap.max_len_even, len);
-            if (k >= 1) tab_sum += len;
+            ap.max_len_slot[k] = std::max(ap.max_len_slot[k], len);
         }
-        ap.max_tab_sum = std::max(ap.max_tab_sum, tab_sum);
     }
     return ap;
 }
@@ -262,11 +262,14 @@ static AxisPlan plan_axis(const std::vector<std::vector<int32_t>>& off, const in
 static size_t pyr_buffer_bytes(size_t area) { return ((area + 15) & ~(size_t)15) + 16; }
 
 // The coefficient slices of a tile lie packed in LDS: every level's x slice (whole dwords of pixels, so
-// multiples of four entries of 4 bytes), then every level's y slice (entries of 2 bytes: 9 bits of weight
+// multiples of four entries of 4 bytes; a level's slice starts where the longest slices of the levels before
+// it end, the same place for every tile), then every level's y slice (entries of 2 bytes: 9 bits of weight
 // and the source row within the staged region, which must fit 7 bits); the chain buffers that follow
 // start on 16 bytes.
 static size_t pyr_table_bytes(const AxisPlan& ax, const AxisPlan& ay) {
-    return ((size_t)ax.max_tab_sum * 4 + (size_t)ay.max_tab_sum * 2 + 15) & ~(size_t)15;
+    size_t nx = 0, ny = 0;
+    for (size_t k = 1; k < ax.max_len_slot.size(); k++) { nx += ax.max_len_slot[k]; ny += ay.max_len_slot[k]; }
+    return 2 * kMaxLevels * sizeof(PyrSpan) + ((nx * 4 + ny * 2 + 15) & ~(size_t)15);   // the tile's spans come first
 }
 
 struct HostGroup { int first, last, T, ntx, nty; AxisPlan ax, ay; size_t lds; };
@@ -389,6 +392,12 @@ static int build_tables(slam_amd_extractor* ex) {
         slam_amd_extractor::PyrGroupPlan pg;
         pg.first = hg.first; pg.last = hg.last; pg.ntx = hg.ntx; pg.nty = hg.nty;
         pg.tab_bytes = (int)pyr_table_bytes(hg.ax, hg.ay);
+        int xat = 0, yat = 0;
+        for (int k = 1; k < (int)hg.ax.max_len_slot.size(); k++) {
+            pg.xat[k] = (short)xat; pg.yat[k] = (short)yat;
+            xat += hg.ax.max_len_slot[k]; yat += hg.ay.max_len_slot[k];
+        }
+        pg.x_entries = xat;
         pg.buf_even = (int)pyr_buffer_bytes((size_t)hg.ax.max_len_even * hg.ay.max_len_even);
         pg.buf_odd = (int)pyr_buffer_bytes((size_t)hg.ax.max_len_odd * hg.ay.max_len_odd);
         pg.spanx = reinterpret_cast<const PyrSpan*>(base + o_sx[i]);
@@ -533,7 +542,8 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
         a.first = pg.first; a.last = pg.last; a.ntx = pg.ntx; a.nty = pg.nty;
         a.spanx = pg.spanx; a.spany = pg.spany;
         for (int l = 1; l < g.nlevels; l++) { a.xtab[l] = ex->xtab[l]; a.ytab[l] = ex->ytab[l]; }
-        a.tab_bytes = pg.tab_bytes; a.buf_even = pg.buf_even; a.buf_odd = pg.buf_odd;
+        a.tab_bytes = pg.tab_bytes; a.x_entries = pg.x_entries;
+        for (int k = 0; k <= kMaxLevels; k++) { a.xat[k] = pg.xat[k]; a.yat[k] = pg.yat[k]; } a.buf_even = pg.buf_even; a.buf_odd = pg.buf_odd;
         if ((rc = launch_pyramid(a, batch, pg.lds_bytes, st))) return rc;
     }
     prof_mark(kStageResize, false, st);

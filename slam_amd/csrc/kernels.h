@@ -14,6 +14,10 @@ struct PyramidArgs {
     int src0_pitch;
     int src0_aligned;          // 1: base and pitches are multiples of 4
     uint8_t* pyr;              // levels >= 1
+    // the source level of this launch, level first - 1 (set by the launcher from the fields above)
+    const uint8_t* src;
+    size_t src_frame_pitch;
+    int src_pitch, src_aligned, src_w, src_h;
     PyrGeom g;
     int first, last;           // levels this launch produces (first >= 1); the source is level first - 1
     int ntx, nty;              // tiles of level `last`
@@ -22,6 +26,9 @@ struct PyramidArgs {
     const uint32_t* xtab[kMaxLevels];  // per level: source index | second-tap weight << 16, padded
     const uint32_t* ytab[kMaxLevels];
     int tab_bytes;             // LDS bytes reserved for a tile's coefficient slices (multiple of 16)
+    int x_entries;             // entries of all x slices together (the y slices follow them)
+    int xat[kMaxLevels + 1];   // first entry of slot k's x slice (4-byte entries) and
+    int yat[kMaxLevels + 1];   // of its y slice (2-byte entries)
     int buf_even, buf_odd;     // bytes of the LDS buffers of the even / odd slots
 };
 
