@@ -34,6 +34,12 @@
 #define SA_STAMP(i)
 #define SA_STAMP_PRINT
 #endif
+#ifndef SA_SEL_EXP
+#define SA_SEL_EXP 0      // build-time experiment switch; 0 in every shipped build
+#endif
+#ifndef SA_SEL_STAMPS
+#define SA_SEL_STAMPS 0   // 1: select_compact prints the clock at its step boundaries for two frames (timing experiments)
+#endif
 #ifndef SA_DESC_STAMPS
 #define SA_DESC_STAMPS 0  // 1: describe prints the clock at its pass boundaries for a few workgroups (timing experiments)
 #endif
@@ -517,32 +523,39 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// Selection + compaction, one workgroup of 16 waves per (frame, level).
+// Selection + compaction, one workgroup of 8 waves per (frame, level) (16 waves measured 5 us slower per launch).
 //   1. KeyPointsFilter::retainBest from the score histograms: wave w takes level
 //      w (levels up to the workgroup's own), suffix sums over the 256 bins by
 //      shuffles -> cut score and kept count.  The level's first output index is
 //      the sum of the kept counts of the lower levels.
 //   2. The kept survivors (score >= cut) of the level's tile lists are gathered into LDS as
-//      keys y << 14 | x, and every one is ranked by counting the smaller keys: its rank is its
-//      place in the canonical (octave, y, x) order.  The kept set of a level is about its quota
-//      (a few hundred to a few thousand keys), so the quadratic count is cheap, needs no sort
-//      and no atomics on the output.  A level with more kept survivors than the LDS cache
-//      holds (long runs of equal scores) is ranked against the tile lists in memory instead.
+//      keys y << 14 | x.  A key's place in the canonical (octave, y, x) order is the number of
+//      kept keys in the rows above it plus those of its own row further left: keys are counted
+//      per row, the counts prefixed, the keys' x grouped by row and compared within the row
+//      (a handful of keys) -- no sort and no atomics on the output.  A level with more kept
+//      survivors than the LDS cache holds (long runs of equal scores) is ranked against the tile
+//      lists in memory instead; one with more rows than the prefix array by counting the smaller
+//      keys, all against all.
 // ---------------------------------------------------------------------------
-constexpr int kSelTileChunk = 4096;   // tiles whose counts are held in LDS at a time
+#ifndef SA_SEL_THREADS
+#define SA_SEL_THREADS 512
+#endif
+constexpr int kSelThreads = SA_SEL_THREADS;        // threads of a select_compact workgroup
+constexpr int kSelTileChunk = 4 * kSelThreads;    // tiles whose counts are held in LDS at a time (four per thread)
+constexpr int kSelPrefCap = 4096;                 // entries of the prefix array: a chunk of tiles, or the rows of a level
+static_assert(kSelTileChunk <= kSelPrefCap && kSelPrefCap % kSelThreads == 0, "prefix array");
 constexpr int kSelKeyCap = 4096;      // kept survivors ranked from LDS
 
 constexpr int kQtCap = 8192;          // survivors of one level the quadtree kernel sorts in LDS
 
-// Selection of every level up to my_level of frame b, one wave per level: cut score and kept
+// Selection of every level up to my_level of frame b, a wave per level (nwaves of them take turns): cut score and kept
 // count of KeyPointsFilter::retainBest from the score histogram (lane owns bins 4 lane ..
 // 4 lane + 3, suffix sums over the bins).  With the quadtree option a level that holds more
 // survivors than its quota (and no more than the quadtree kernel sorts) keeps exactly the quota
 // and is marked mode 1: the quadtree kernel writes it, the plain kernel skips it.
-__device__ __forceinline__ void level_selection(const SelectCompactArgs& a, int b, int my_level, int wave, int lane,
+__device__ __forceinline__ void level_selection(const SelectCompactArgs& a, int b, int my_level, int wave, int nwaves, int lane,
                                                 int* s_cut, int* s_cnt, int* s_mode) {
-    if (wave <= my_level) {
-        const int l = wave;
+    for (int l = wave; l <= my_level; l += nwaves) {
         const unsigned* h = a.hist + ((size_t)b * a.g.nlevels + l) * 256;
         const unsigned v0 = h[4 * lane], v1 = h[4 * lane + 1], v2 = h[4 * lane + 2], v3 = h[4 * lane + 3];
         const unsigned own = v0 + v1 + v2 + v3;
@@ -579,31 +592,86 @@ __device__ __forceinline__ void level_selection(const SelectCompactArgs& a, int 
     }
 }
 
-__global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs a) {
+// Exclusive prefix over kSelThreads * R values, thread t holding values R t .. R t + R - 1: returns the
+// prefix of the thread's first value; `total` is the sum of all.  Synchronises the workgroup (twice).
+template <int R>
+__device__ __forceinline__ unsigned select_block_scan(const unsigned (&c)[R], unsigned* s_wave, unsigned& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned sum = 0;
+#pragma unroll
+    for (int k = 0; k < R; k++) sum += c[k];
+    unsigned inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    __syncthreads();              // s_wave of an earlier scan has been read
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    unsigned before = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < kSelThreads / 64; w++) {
+        const unsigned v = s_wave[w];
+        if (w < wave) before += v;
+        total += v;
+    }
+    return before + inc - sum;
+}
+
+__global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompactArgs a) {
     __shared__ int s_cut[kMaxLevels], s_cnt[kMaxLevels], s_mode[kMaxLevels];
-    __shared__ unsigned s_wave[16];
-    __shared__ unsigned s_pref[kSelTileChunk + 1];
+    __shared__ unsigned s_wave[kSelThreads / 64];
+    __shared__ unsigned s_pref[kSelPrefCap + 1];      // tile prefix while gathering, row prefix while ranking
     __shared__ __align__(16) unsigned s_key[kSelKeyCap];
+    __shared__ uint16_t s_rowx[kSelKeyCap];           // the kept keys' x, grouped by row
     __shared__ uint8_t s_score[kSelKeyCap];
     __shared__ unsigned s_n;
+    // Workgroups go round-robin over the 8 XCDs; the level is rotated by the frame so that every XCD
+    // gets all levels (with 8 levels and level = blockIdx % 8, one XCD would get every frame's level 0,
+    // the longest lists, and another every frame's top level).
     const int b = blockIdx.x / a.g.nlevels;
-    const int my_level = blockIdx.x - b * a.g.nlevels;
+    const int my_level = (int)((blockIdx.x + (unsigned)b) % (unsigned)a.g.nlevels);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_n = 0;
-    level_selection(a, b, my_level, wave, lane, s_cut, s_cnt, s_mode);
-    __syncthreads();
-
+#if SA_SEL_STAMPS
+    unsigned long long sst[6] = {};
+    sst[0] = __builtin_amdgcn_s_memtime();
+#endif
+#if SA_SEL_EXP == 1
+    if (a.capacity > 0) return;     // experiment: what launching the grid costs
+#endif
     const int l = my_level;
     const LevelGeom& L = a.g.lv[l];
+    const int tiles_x = L.tiles_x, ntl = tiles_x * div_up_dev(L.h, kFastTileH);
+    const unsigned* tcount = a.tilecount + (size_t)b * a.g.total_tiles + L.tile_base;
+    const uint32_t* tlist = a.tilelist + ((size_t)b * a.g.total_tiles + L.tile_base) * kTileListCap;
+    // survivor counts of four tiles per thread; the first chunk's are fetched together with the histograms
+    unsigned c4[4];
+    auto load_counts = [&](int chunk0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int t = chunk0 + tid * 4 + k;
+            c4[k] = t < ntl ? min(tcount[t], (unsigned)kTileListCap) : 0u;
+        }
+    };
+    load_counts(0);
+    if (tid == 0) s_n = 0;
+    level_selection(a, b, my_level, wave, kSelThreads / 64, lane, s_cut, s_cnt, s_mode);
+    __syncthreads();
+#if SA_SEL_EXP == 2
+    if (a.capacity > 0) return;     // experiment: launch + selection
+#endif
+#if SA_SEL_STAMPS
+    sst[1] = __builtin_amdgcn_s_memtime();
+#endif
+
     const unsigned cut = (unsigned)s_cut[l];
     const int kept = s_cnt[l];
     int base = 0;                         // keypoints of the lower levels
     for (int i = 0; i < l; i++) base += s_cnt[i];
     slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity;
     uint32_t* kpxy = a.kpxy + (size_t)b * a.capacity;
-    const int tiles_x = L.tiles_x, ntl = tiles_x * div_up_dev(L.h, kFastTileH);
-    const unsigned* tcount = a.tilecount + (size_t)b * a.g.total_tiles + L.tile_base;
-    const uint32_t* tlist = a.tilelist + ((size_t)b * a.g.total_tiles + L.tile_base) * kTileListCap;
     const bool cached = kept <= a.keycap;   // uniform
 
     auto emit = [&](unsigned key, unsigned sc, int rank) {
@@ -632,30 +700,13 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs 
     if (kept > 0 && cut < 256 && s_mode[l] == 0) {
         for (int chunk0 = 0; chunk0 < ntl; chunk0 += kSelTileChunk) {
             const int nt = min(kSelTileChunk, ntl - chunk0);
-            // exclusive prefix of the tiles' survivor counts: four tiles per thread
-            unsigned c4[4], sum = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int t = tid * 4 + k;
-                c4[k] = t < nt ? min(tcount[chunk0 + t], (unsigned)kTileListCap) : 0u;
-                sum += c4[k];
+            if (chunk0 > 0) {
+                __syncthreads();          // s_pref of the chunk before has been read
+                load_counts(chunk0);
             }
-            unsigned inc = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned v = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += v;
-            }
-            __syncthreads();              // s_pref / s_wave of the previous chunk have been read
-            if (lane == 63) s_wave[wave] = inc;
-            __syncthreads();
-            unsigned before = 0, total = 0;
-            for (int w = 0; w < 16; w++) {
-                const unsigned v = s_wave[w];
-                if (w < wave) before += v;
-                total += v;
-            }
-            unsigned run = before + inc - sum;
+            // exclusive prefix of the tiles' survivor counts
+            unsigned total;
+            unsigned run = select_block_scan<4>(c4, s_wave, total);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (tid * 4 + k < nt) s_pref[tid * 4 + k] = run;
@@ -663,52 +714,120 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(SelectCompactArgs 
             }
             if (tid == 0) s_pref[nt] = total;
             __syncthreads();
-            // every entry of the chunk's lists, flat; its tile by binary search in the prefix
-            for (unsigned e = tid; e < total; e += 1024) {
-                int lo = 0, hi = nt;      // largest t with s_pref[t] <= e
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_pref[mid] <= e) lo = mid; else hi = mid;
-                }
-                const uint32_t ent = tlist[(size_t)(chunk0 + lo) * kTileListCap + (e - s_pref[lo])];
-                const unsigned sc = ent >> 16;
-                if (sc < cut) continue;
-                const unsigned key = key_of(chunk0 + lo, ent);
-                if (cached) {
-                    const unsigned slot = atomicAdd(&s_n, 1u);
-                    if (slot < (unsigned)kSelKeyCap) { s_key[slot] = key; s_score[slot] = (uint8_t)sc; }
-                } else {
-                    // rank against the lists in memory: every kept entry of the level with a smaller key
-                    int rank = 0;
-                    for (int t = 0; t < ntl; t++) {
-                        const unsigned n = min(tcount[t], (unsigned)kTileListCap);
-                        const uint32_t* p = tlist + (size_t)t * kTileListCap;
-                        for (unsigned j = 0; j < n; j++) {
-                            const uint32_t o = p[j];
-                            rank += ((o >> 16) >= cut) && (key_of(t, o) < key);
-                        }
+#if SA_SEL_STAMPS
+            sst[2] = __builtin_amdgcn_s_memtime();
+#endif
+            // every entry of the chunk's lists, flat; its tile by binary search in the prefix.  Several
+            // entries per thread and trip, so that their loads are in flight together (an entry past
+            // the end reads as score 0, below every cut).
+#ifndef SA_SEL_GATHER
+#define SA_SEL_GATHER 5
+#endif
+            constexpr int kGather = SA_SEL_GATHER;
+            for (unsigned e0 = 0; e0 < total; e0 += kGather * kSelThreads) {
+                uint32_t ent[kGather];
+                int tile[kGather];
+#pragma unroll
+                for (int u = 0; u < kGather; u++) {
+                    const unsigned e = e0 + (unsigned)(u * kSelThreads + tid);
+                    int lo = 0, hi = nt;      // largest t with s_pref[t] <= e
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_pref[mid] <= e) lo = mid; else hi = mid;
                     }
-                    emit(key, sc, rank);
+                    tile[u] = chunk0 + lo;
+                    ent[u] = e < total ? tlist[(size_t)(chunk0 + lo) * kTileListCap + (e - s_pref[lo])] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < kGather; u++) {
+                    const unsigned sc = ent[u] >> 16;
+                    if (sc < cut) continue;
+                    const unsigned key = key_of(tile[u], ent[u]);
+                    if (cached) {
+                        // one atomic per wave: the lanes' atomics on the one counter would be served one by one
+                        const unsigned long long m = __ballot(true);
+                        const int leader = __builtin_ctzll(m);
+                        unsigned slot = 0;
+                        if (lane == leader) slot = atomicAdd(&s_n, (unsigned)__builtin_popcountll(m));
+                        slot = __shfl(slot, leader, 64) + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                        if (slot < (unsigned)kSelKeyCap) { s_key[slot] = key; s_score[slot] = (uint8_t)sc; }
+                    } else {
+                        // rank against the lists in memory: every kept entry of the level with a smaller key
+                        int rank = 0;
+                        for (int t = 0; t < ntl; t++) {
+                            const unsigned n = min(tcount[t], (unsigned)kTileListCap);
+                            const uint32_t* p = tlist + (size_t)t * kTileListCap;
+                            for (unsigned j = 0; j < n; j++) {
+                                const uint32_t o = p[j];
+                                rank += ((o >> 16) >= cut) && (key_of(t, o) < key);
+                            }
+                        }
+                        emit(key, sc, rank);
+                    }
                 }
             }
         }
         if (cached) {
             __syncthreads();
+#if SA_SEL_STAMPS
+            sst[3] = __builtin_amdgcn_s_memtime();
+#endif
             const int n = (int)min(s_n, (unsigned)kSelKeyCap);
-            // pad to a multiple of 4 with keys larger than any real one
-            if (tid < 4 && n + tid < kSelKeyCap) s_key[n + tid] = 0xffffffffu;
-            __syncthreads();
-            for (int i = tid; i < n; i += 1024) {
-                const unsigned key = s_key[i];
-                int rank = 0;
-                for (int j = 0; j < n; j += 4) {
-                    const uint4 k4 = *reinterpret_cast<const uint4*>(&s_key[j]);
-                    rank += (k4.x < key) + (k4.y < key) + (k4.z < key) + (k4.w < key);
+            if (L.h <= kSelPrefCap) {
+                // Rank = keys in the rows above + keys of the same row further left: count the keys of
+                // every row, prefix over the rows, group the keys' x by row, compare within the row.
+                constexpr int R = kSelPrefCap / kSelThreads;
+#pragma unroll
+                for (int k = 0; k < R; k++) s_pref[tid + k * kSelThreads] = 0;
+                __syncthreads();
+                for (int i = tid; i < n; i += kSelThreads) atomicAdd(&s_pref[s_key[i] >> 14], 1u);
+                __syncthreads();
+                unsigned r[R];
+#pragma unroll
+                for (int k = 0; k < R; k++) r[k] = s_pref[tid * R + k];
+                unsigned rows_total;
+                unsigned run = select_block_scan<R>(r, s_wave, rows_total);
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    s_pref[tid * R + k] = run;       // first place of row tid R + k ...
+                    run += r[k];
                 }
-                emit(key, s_score[i], rank);
+                __syncthreads();
+                for (int i = tid; i < n; i += kSelThreads) {
+                    const unsigned key = s_key[i];
+                    s_rowx[atomicAdd(&s_pref[key >> 14], 1u)] = (uint16_t)(key & 0x3fffu);   // ... and now one past its last
+                }
+                __syncthreads();
+                for (int i = tid; i < n; i += kSelThreads) {
+                    const unsigned key = s_key[i];
+                    const unsigned y = key >> 14, x = key & 0x3fffu;
+                    const unsigned first = y ? s_pref[y - 1] : 0u, last = s_pref[y];
+                    int rank = (int)first;
+                    for (unsigned j = first; j < last; j++) rank += s_rowx[j] < x;
+                    emit(key, s_score[i], rank);
+                }
+            } else {
+                // a level with more rows than the prefix array holds: count the smaller keys, all against all
+                if (tid < 4 && n + tid < kSelKeyCap) s_key[n + tid] = 0xffffffffu;   // pad to a multiple of 4
+                __syncthreads();
+                for (int i = tid; i < n; i += kSelThreads) {
+                    const unsigned key = s_key[i];
+                    int rank = 0;
+                    for (int j = 0; j < n; j += 4) {
+                        const uint4 k4 = *reinterpret_cast<const uint4*>(&s_key[j]);
+                        rank += (k4.x < key) + (k4.y < key) + (k4.z < key) + (k4.w < key);
+                    }
+                    emit(key, s_score[i], rank);
+                }
             }
         }
     }
+#if SA_SEL_STAMPS
+    sst[4] = __builtin_amdgcn_s_memtime();
+    if (tid == 0 && my_level == 0)
+        printf("select start %llu end %llu frame %d level %d kept %d entries %u : selection %llu prefix %llu gather %llu rank+emit %llu\n", sst[0] & 0xfffffffull, sst[4] & 0xfffffffull, b, my_level, s_cnt[my_level],
+               (unsigned)s_n, sst[1] - sst[0], sst[2] - sst[1], sst[3] - sst[2], sst[4] - sst[3]);
+#endif
     // the workgroup of the top level has every level's count: it publishes the totals
     if (threadIdx.x == 0 && my_level == a.g.nlevels - 1) {
         FrameSelect fs;
@@ -750,7 +869,7 @@ __global__ __launch_bounds__(1024) void quadtree_select_kernel(SelectCompactArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { s_n = 0; s_nc = 0; s_nw = 0; }
     if (tid < 32) s_hc[tid] = 0;
-    level_selection(a, b, l, wave, lane, s_cut, s_cnt, s_mode);
+    level_selection(a, b, l, wave, 16, lane, s_cut, s_cnt, s_mode);
     __syncthreads();
     if (s_mode[l] != 1) return;
     const LevelGeom& L = a.g.lv[l];
@@ -1248,7 +1367,7 @@ int launch_fast(const FastArgs& a0, int batch, hipStream_t st) {
 }
 
 int launch_select_compact(const SelectCompactArgs& a, int batch, hipStream_t st) {
-    hipLaunchKernelGGL(select_compact_kernel, dim3(batch * a.g.nlevels), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(select_compact_kernel, dim3(batch * a.g.nlevels), dim3(kSelThreads), 0, st, a);
     SA_HIP(hipGetLastError());
     if (a.quadtree) {
         hipLaunchKernelGGL(quadtree_select_kernel, dim3(batch * a.g.nlevels), dim3(1024), 0, st, a);
