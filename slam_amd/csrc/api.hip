@@ -551,7 +551,7 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     fa.img0 = d_images; fa.img0_frame_pitch = frame_pitch; fa.img0_pitch = row_stride; fa.img0_aligned = aligned;
     fa.pyr = ex->pyr.as<uint8_t>(); fa.blur = ex->blur.as<uint8_t>(); fa.hist = ex->hist.as<unsigned>();
     fa.tilecount = ex->tilecount.as<unsigned>(); fa.tilelist = ex->tilelist.as<uint32_t>(); fa.g = g;
-    fa.grid_shift = ex->grid_shift; fa.tiledesc = ex->tiledesc.as<uint32_t>(); fa.tiles_eighth = 0;
+    fa.grid_shift = ex->grid_shift; fa.tiledesc = ex->tiledesc.as<uint32_t>(); fa.tiles_eighth = 0; fa.frames_by_xcd = 0;
     { ProfScope ps(kStageFast, st); if ((rc = launch_fast(fa, batch, st))) return rc; }
     SelectCompactArgs sc;
     sc.hist = ex->hist.as<unsigned>(); sc.tilecount = ex->tilecount.as<unsigned>(); sc.tilelist = ex->tilelist.as<uint32_t>();

@@ -17,6 +17,9 @@
 #ifndef SA_DESC_EXP
 #define SA_DESC_EXP 0
 #endif
+#ifndef SA_FAST_FRAMES_BY_XCD
+#define SA_FAST_FRAMES_BY_XCD 1
+#endif
 #ifndef SA_FAST_EXP
 #define SA_FAST_EXP 0     // 1: fast_nms prints the clock at its phase boundaries for a few workgroups (timing experiments)
 #endif
@@ -180,8 +183,16 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     // share halo lines run on the same L2 instead of fetching them once per XCD.  The tile's level
     // and place come from a table: no search over the levels, no division (scalar instructions
     // take issue cycles from the vector ones, and every wave of the workgroup repeats them).
-    const int b = blockIdx.y;
-    const int ftile = (int)(blockIdx.x & 7u) * a.tiles_eighth + (int)(blockIdx.x >> 3);
+    int b, ftile;
+    if (a.frames_by_xcd) {
+        // a multiple of 8 frames: XCD k takes whole frames (k, k + 8, ...): every XCD gets the same mix of
+        // heavy (level 0, interior) and light (top levels, mostly border) tiles, and a frame stays in one L2
+        b = (int)blockIdx.y * 8 + (int)(blockIdx.x & 7u);
+        ftile = (int)(blockIdx.x >> 3);
+    } else {
+        b = blockIdx.y;
+        ftile = (int)(blockIdx.x & 7u) * a.tiles_eighth + (int)(blockIdx.x >> 3);
+    }
     if (ftile >= a.g.total_tiles) return;
     const uint32_t td = a.tiledesc[ftile];
     const int l = (int)(td & 15u), txi = (int)((td >> 4) & 0xfffu), tyi = (int)(td >> 16);
@@ -1360,7 +1371,9 @@ int launch_fast(const FastArgs& a0, int batch, hipStream_t st) {
     FastArgs a = a0;
     a.tiles_eighth = div_up(a.g.total_tiles, 8);
     if (batch > 65535) SA_FAIL(SLAM_AMD_ERR_ARG, "fast: batch too large for one launch");
+    a.frames_by_xcd = SA_FAST_FRAMES_BY_XCD && batch % 8 == 0;
     dim3 grid(a.tiles_eighth * 8, batch);
+    if (a.frames_by_xcd) grid = dim3(a.g.total_tiles * 8, batch / 8);
     hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
