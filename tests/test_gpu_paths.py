@@ -59,6 +59,33 @@ def test_extract_batch_async_with_padding_and_offset(oracle, capi):
         ex.close()
 
 
+def test_extract_batches_of_8_and_other_sizes_on_one_extractor(oracle, capi):
+    """A multiple of 8 frames runs the corner kernel on a grid of its own (whole frames per XCD); the same
+    extractor then takes 5 and 16 frames: every frame of every call against the oracle."""
+    torch = _torch()
+    W, H, NF, CAP, MAXB = 200, 152, 300, 1024, 16
+    frames = [synth.scene(W, H, 70 + i) for i in range(MAXB)]
+    po = oracle.params(nfeatures=NF)
+    want = [oracle.detect_and_compute(po, f) for f in frames]
+    ex = capi.Extractor(capi.orb_params(nfeatures=NF), W, H, max_batch=MAXB, max_keypoints=CAP)
+    d_img = torch.from_numpy(np.stack(frames)).cuda()
+    for B in (8, 5, 16):
+        d_kp = torch.zeros(B * CAP * KP, dtype=torch.uint8, device="cuda")
+        d_desc = torch.zeros(B * CAP * 32, dtype=torch.uint8, device="cuda")
+        d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+        ex.extract_batch_async(d_img.data_ptr(), B, W * H, W, d_kp, d_desc, d_cnt, CAP, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        cnt = d_cnt.cpu().numpy()
+        kp_all = d_kp.cpu().numpy().view(capi.KEYPOINT_DTYPE)
+        d_all = d_desc.cpu().numpy().reshape(B * CAP, 32)
+        for b in range(B):
+            kp_o, d_o = want[b]
+            assert cnt[b] == len(kp_o), (B, b)
+            assert kp_all[b * CAP: b * CAP + cnt[b]].tobytes() == kp_o.tobytes(), (B, b)
+            assert np.array_equal(d_all[b * CAP: b * CAP + cnt[b]], d_o), (B, b)
+    ex.close()
+
+
 def test_extract_capacity_and_errors(oracle, capi):
     torch = _torch()
     img = synth.scene(320, 240, 31)
