@@ -188,11 +188,12 @@ static int build_geometry_of(const slam_amd_orb_params& p, int width, int height
         L.off = off;
         L.row_base = rows;
         L.tile_base = tiles;
-        off += (unsigned)L.pitch * (unsigned)L.h;
+        off += (unsigned)L.pitch * (unsigned)((L.h + kBlurTileH - 1) / kBlurTileH * kBlurTileH);   // whole tile rows of the blurred copy
         rows += L.h;
         tiles += L.tiles_x * div_up(L.h, kFastTileH);
     }
-    g.frame_bytes = (off + 255u) & ~255u;
+    // (the descriptor kernel's 64-byte-wide fetches may run up to three tiles past the last one it needs)
+    g.frame_bytes = (off + 3u * 128u + 255u) & ~255u;
     g.total_rows = rows;
     g.total_tiles = tiles;
     return SLAM_AMD_OK;
@@ -632,9 +633,17 @@ static int debug_level(slam_amd_extractor* ex, int frame, int level, bool blurre
         if (!ex->last_img0) SA_FAIL(SLAM_AMD_ERR_ARG, "no batch has been processed yet");
         SA_HIP(hipMemcpy2D(host_out, host_stride, ex->last_img0 + (size_t)frame * ex->last_frame_pitch,
                            ex->last_row_stride, L.w, L.h, hipMemcpyDeviceToHost));
+    } else if (blurred) {
+        // stored in tiles: fetch the level's whole tile rows and put the pixels back in rows
+        const int rows8 = (L.h + kBlurTileH - 1) / kBlurTileH * kBlurTileH;
+        std::vector<uint8_t> tiled((size_t)L.pitch * rows8);
+        SA_HIP(hipMemcpy(tiled.data(), ex->blur.as<uint8_t>() + (size_t)frame * ex->g.frame_bytes + L.off, tiled.size(),
+                         hipMemcpyDeviceToHost));
+        for (int y = 0; y < L.h; y++)
+            for (int x = 0; x < L.w; x++)
+                host_out[(size_t)y * host_stride + x] = tiled[blur_tiled_offset((unsigned)L.pitch, (unsigned)x, (unsigned)y)];
     } else {
-        const uint8_t* base = blurred ? ex->blur.as<uint8_t>() : ex->pyr.as<uint8_t>();
-        SA_HIP(hipMemcpy2D(host_out, host_stride, base + (size_t)frame * ex->g.frame_bytes + L.off, L.pitch,
+        SA_HIP(hipMemcpy2D(host_out, host_stride, ex->pyr.as<uint8_t>() + (size_t)frame * ex->g.frame_bytes + L.off, L.pitch,
                            L.w, L.h, hipMemcpyDeviceToHost));
     }
     return SLAM_AMD_OK;

@@ -41,6 +41,14 @@ struct LevelGeom {
     float size;         // keypoint size at this level: patch_size * scale
 };
 
+// The blurred levels are stored in tiles of 16 x 8 pixels (128 bytes, rows of a tile one after the other;
+// a level's rows are padded to a multiple of 8 and its pitch is a multiple of 64): the descriptor kernel
+// fetches square patches, and a 64-byte piece of the address space then holds 16 x 4 pixels instead of 64 x 1.
+constexpr int kBlurTileW = 16, kBlurTileH = 8;
+__host__ __device__ inline unsigned blur_tiled_offset(unsigned pitch, unsigned x, unsigned y) {
+    return (((y >> 3) * (pitch >> 4) + (x >> 4)) << 7) + ((y & 7u) << 4) + (x & 15u);
+}
+
 struct PyrGeom {
     int nlevels;
     int edge;           // edge threshold

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             const unsigned o3 = dot2(B.x, 18u | 49u << 16, dot2(B.y, 34u | 55u << 16, dot2(C.x, 49u | 18u << 16, dot2(C.y, 34u, rnd))));
             // byte 2 of o0 .. o3 -> bytes 0 .. 3
             const unsigned lo = __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u), hi = __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);
-            if (gy < h) *reinterpret_cast<uint32_t*>(blur + (size_t)gy * L.pitch + x0 + 4 * og) = lo | hi;
+            if (gy < h) *reinterpret_cast<uint32_t*>(blur + blur_tiled_offset((unsigned)L.pitch, (unsigned)(x0 + 4 * og), (unsigned)gy)) = lo | hi;
         }
     }
     SA_STAMP(10);
@@ -1093,6 +1093,7 @@ __global__ __launch_bounds__(1024) void quadtree_select_kernel(SelectCompactArgs
 constexpr int kURad = 15, kURows = 31;
 constexpr int kBRad = 18, kBRows = 37;
 constexpr int kPPitch = 64;        // LDS bytes per row of the blurred patch
+constexpr int kBLoadRows = 48;     // rows fetched at most: from the tile row that holds the patch's first row (up to 7 rows above it)
 
 // rBRIEF sampling pattern as floats: x0, y0, x1, y1 of pair p at [4 * p].
 __constant__ __align__(16) float c_pattern[256 * 4] = {
@@ -1169,7 +1170,7 @@ constexpr int kDescKps = SA_DESC_KPS;                   // keypoints per (single
 constexpr int kDescAhead = SA_DESC_AHEAD < SA_DESC_KPS ? SA_DESC_AHEAD : SA_DESC_KPS;   // blurred patches in flight
 
 __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
-    __shared__ __align__(16) uint8_t s_patch[kBRows * kPPitch];
+    __shared__ __align__(16) uint8_t s_patch[kBLoadRows * kPPitch];
     // 1-D grid, frame index fastest, so the workgroups beyond the last keypoint of
     // every frame (they exit at once) sit at the end of the grid.
     SA_DSTAMP_DECL;
@@ -1218,11 +1219,13 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
     const int bpitch = okv ? lpitch : 0;
     const unsigned long long uaddr = reinterpret_cast<uintptr_t>(
         okv ? ulevel + (ptrdiff_t)(py - kURad) * upitch + (px - kURad) : a.pyr + (size_t)b * a.g.frame_bytes);
-    const unsigned long long bfirst = reinterpret_cast<uintptr_t>(
-        okv ? a.blur + (size_t)b * a.g.frame_bytes + loff + (ptrdiff_t)(py - kBRad) * lpitch + (px - kBRad)
-            : a.blur + (size_t)b * a.g.frame_bytes);
-    const unsigned long long baddr = bfirst & ~15ull;     // the blurred patch is fetched from the 16-byte boundary before it
-    const int bshift = (int)(bfirst & 15ull);
+    // The blurred level lies in tiles of 16 x 8 pixels.  The patch is fetched from the tile that holds its
+    // first pixel: whole 16-byte tile rows, four tiles across, up to 7 rows above the patch and 15 columns
+    // left of it coming along (bshift, yshift: where the patch starts in what was fetched).
+    const int bx0 = px - kBRad, by0 = py - kBRad;
+    const int bshift = okv ? (bx0 & 15) : 0, yshift = okv ? (by0 & 7) : 0;
+    const unsigned long long baddr = reinterpret_cast<uintptr_t>(
+        a.blur + (size_t)b * a.g.frame_bytes + (okv ? loff + blur_tiled_offset((unsigned)lpitch, (unsigned)(bx0 & ~15), (unsigned)(by0 & ~7)) : 0u));
     const int ualo = (int)(unsigned)uaddr, uahi = (int)(unsigned)(uaddr >> 32);
     const int balo = (int)(unsigned)baddr, bahi = (int)(unsigned)(baddr >> 32);
     auto patch_base = [&](int alo, int ahi, int j) {
@@ -1285,23 +1288,27 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
         float4 pat[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) pat[k] = reinterpret_cast<const float4*>(c_pattern)[64 * k + lane];
-        // Rows of 64 bytes that start at the 16-byte boundary at or before the patch's first column (the
-        // address unit takes four aligned 16-byte lanes of one line per cycle, but one lane at a time where
-        // they are not aligned); lane = 4 x row + chunk, 16 rows per load, the third load rows 32-36.
-        // The rows of the blurred level are 64-byte aligned, so the patch starts at the same column
-        // of every row of s_patch.
-        const int brow = lane >> 2, bchunk = lane & 3;
-        const bool third_rows = 2 * 16 + brow < kBRows;           // lanes 0-19
-        uint8_t* const w0 = s_patch + 16 * lane;
+        // Rows of 64 bytes from the 16-byte column at or before the patch's first one, 16 rows per load, the
+        // third load as far as the patch reaches (what a load costs the address unit is the number of
+        // (quad of lanes, 64-byte line) pairs it touches: in the tiled level four rows of a 16-byte column
+        // are one aligned line).  The patch starts at the same column of every row of s_patch.
+        // lane -> (row of a 16-row load, 16-byte column): a quad of lanes takes four rows of one tile,
+        // 64 consecutive bytes, and 16 consecutive lanes fill 256 consecutive bytes of s_patch
+        // (eight rows of a column per eight lanes - a whole 128-byte tile - measured slower: those 16 lanes
+        // write s_patch with two-way bank conflicts)
+        const int brow = 4 * (lane >> 4) + (lane & 3), bchunk = (lane >> 2) & 3;
+        uint8_t* const w0 = s_patch + brow * kPPitch + 16 * bchunk;
         struct PatchRegs { u32x4 v0, v1, v2; };
         auto load_b = [&](int j) {
             global_bytes_t base = patch_base(balo, bahi, j);
-            const unsigned pitch = (unsigned)__builtin_amdgcn_readlane(bpitch, j);
-            const unsigned at = __umul24((unsigned)brow, pitch) + 16u * (unsigned)bchunk;
+            const unsigned pitch8 = (unsigned)__builtin_amdgcn_readlane(bpitch, j) * 8u;   // bytes from one tile row to the next
+            const int rows = __builtin_amdgcn_readlane(yshift, j) + kBRows;               // rows of the fetch that the patch reaches
+            const unsigned at = ((brow & 8) ? pitch8 : 0u) + 128u * (unsigned)bchunk + 16u * (unsigned)(brow & 7);
             PatchRegs r;
             r.v0 = *(global_u4_t)(base + at);
-            r.v1 = *(global_u4_t)(base + (at + 16u * pitch));
-            if (third_rows) r.v2 = *(global_u4_t)(base + (at + 32u * pitch));
+            r.v1 = *(global_u4_t)(base + (at + 2u * pitch8));
+            r.v2 = u32x4{0u, 0u, 0u, 0u};
+            if (32 + brow < rows) r.v2 = *(global_u4_t)(base + (at + 4u * pitch8));
             return r;
         };
         // LDS traffic of one wave executes in order; this only keeps the compiler from moving LDS
@@ -1331,13 +1338,13 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
         for (int j = 0; j < kDescKps; j++) {
             *reinterpret_cast<u32x4*>(w0) = ahead[j % kDescAhead].v0;
             *reinterpret_cast<u32x4*>(w0 + 1024) = ahead[j % kDescAhead].v1;
-            if (third_rows) *reinterpret_cast<u32x4*>(w0 + 2048) = ahead[j % kDescAhead].v2;
+            *reinterpret_cast<u32x4*>(w0 + 2048) = ahead[j % kDescAhead].v2;
             if (j + kDescAhead < kDescKps) ahead[j % kDescAhead] = load_b(min(j + kDescAhead, nk - 1));
             lds_order();
             // (copies in vector registers: an instruction with a scalar-register operand issues at half rate)
             float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cav), j));
             float sn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, snv), j));
-            unsigned origin = s_base + (unsigned)__builtin_amdgcn_readlane(bshift, j);
+            unsigned origin = s_base + (unsigned)__builtin_amdgcn_readlane(bshift + (yshift << 6), j);
             asm volatile("v_mov_b32 %0, %0" : "+v"(ca));
             asm volatile("v_mov_b32 %0, %0" : "+v"(sn));
             asm volatile("v_mov_b32 %0, %0" : "+v"(origin));
