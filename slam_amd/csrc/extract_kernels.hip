@@ -1165,9 +1165,9 @@ typedef const __attribute__((address_space(1))) u32x4_a1* global_u4_t;
 #endif
 constexpr int kDescKps = SA_DESC_KPS;                   // keypoints per (single-wave) workgroup
 #ifndef SA_DESC_AHEAD
-#define SA_DESC_AHEAD 4
+#define SA_DESC_AHEAD 3
 #endif
-constexpr int kDescAhead = SA_DESC_AHEAD < SA_DESC_KPS ? SA_DESC_AHEAD : SA_DESC_KPS;   // blurred patches in flight
+constexpr int kDescAhead = SA_DESC_AHEAD < SA_DESC_KPS ? SA_DESC_AHEAD : SA_DESC_KPS;   // blurred patches in flight (3: 90 registers, 5 waves per SIMD; 4: 101, 4 waves, 3 us slower)
 
 __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
     __shared__ __align__(16) uint8_t s_patch[kBLoadRows * kPPitch];
