@@ -84,13 +84,13 @@ namespace sa {
 // ---------------------------------------------------------------------------
 constexpr int kImgHalo = 4;
 constexpr int kImgDw = (kFastTileW + 2 * kImgHalo) / 4;   // 18 staged dwords per row
-constexpr int kImgPitch = 4 * (kImgDw + 1);               // 76 bytes: 19 dwords per row, odd, so that the
-                                                          // rows of a column fall into different LDS banks
+constexpr int kImgPitch = 4 * kImgDw;                     // 72 bytes
 constexpr int kImgRows = kFastTileH + 2 * kImgHalo;   // 40
-constexpr int kEoPitch = kImgDw + 2;                  // split tile: a zero entry on either side of the 18 groups
+constexpr int kEoPitch = kImgDw + 1;                  // split tile: a zero entry before the 18 groups of a row (the one
+                                                      // after them is the next row's; one more closes the last row)
 constexpr int kScW = kFastTileW + 2;                  // 66 scored columns
 constexpr int kScRows = kFastTileH + 2;               // 34 scored rows
-constexpr int kScPitch = kImgPitch;                   // LDS column = tile column + 4
+constexpr int kScPitch = kScW;                        // score map: scored row r, column c at r * 66 + c (staged row r + 3, column c + 3)
 constexpr int kScN = kScW * kScRows;                  // 2244 positions
 constexpr int kScBytes = ((kScRows * kScPitch + 15) / 16) * 16;
 constexpr int kListBytes = ((kScN * 2 + 15) / 16) * 16;
@@ -160,12 +160,11 @@ __device__ __forceinline__ unsigned dot2(unsigned a, unsigned b, unsigned c) {
 
 __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     __shared__ __align__(16) uint8_t s_img[kImgRows * kImgPitch];
-    __shared__ __align__(16) uint2 s_eo[kImgRows * kEoPitch];       // {even, odd} columns of every staged dword
+    __shared__ __align__(16) uint2 s_eo[kImgRows * kEoPitch + 1];   // {even, odd} columns of every staged dword
     __shared__ __align__(16) uint8_t s_sc[kScBytes];
     // list 1 (phases 1-2) and the vertical-pass result of the blur (phases 3-4) share one region
     __shared__ __align__(16) uint8_t s_scratch[kFastTileH * kVPitch * 4];
     __shared__ __align__(16) uint16_t s_list2[kListBytes / 2];
-    __shared__ unsigned s_hist[256];
     __shared__ unsigned s_n[3];   // lengths of list 1, list 2 and the survivor list
     __shared__ unsigned s_cellbest[(kFastTileW / 8) * (kFastTileH / 8)];   // grid cells of >= 8 x 8 pixels
     uint16_t* s_list1 = reinterpret_cast<uint16_t*>(s_scratch);
@@ -173,9 +172,11 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     // this tile's survivors, lx | ly << 6 | score << 16, over the split tile (dead once the vertical blur pass is done)
     uint32_t* s_surv = reinterpret_cast<uint32_t*>(s_eo);
     static_assert(kTileListCap * 4 <= (int)sizeof(s_eo), "survivor list must fit the split tile");
-    static_assert(kScPitch == kImgPitch, "score tile and image tile share one pitch");
     static_assert(kListBytes <= (int)sizeof(s_scratch), "list 1 must fit the scratch region");
     constexpr int P = kImgPitch;
+    // 8 workgroups per CU need 160 KB / 8 each; the kernel gains 4 % over 7 (and loses 27 % at 5)
+    static_assert(sizeof(s_img) + sizeof(s_eo) + sizeof(s_sc) + sizeof(s_scratch) + sizeof(s_list2) + sizeof(s_n) + sizeof(s_cellbest) <= 20480,
+                  "LDS of fast_nms");
 
     // Grid: x = tile slot of a frame (a multiple of 8 of them), y = frame.  Workgroups are dealt
     // round-robin over the 8 XCDs, each with its own L2, in x-fastest order, so XCD k sees the slots
@@ -214,11 +215,10 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     const int tid = threadIdx.x;
     SA_STAMP_DECL;
     SA_STAMP(0);
-    s_hist[tid] = 0;
     if (tid < 3) s_n[tid] = 0;
     if (tid < (kFastTileW / 8) * (kFastTileH / 8)) s_cellbest[tid] = 0;
     if (tid < kScBytes / 16) reinterpret_cast<uint4*>(s_sc)[tid] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid < 2 * kImgRows) s_eo[(tid >> 1) * kEoPitch + (tid & 1) * (kEoPitch - 1)] = make_uint2(0u, 0u);
+    if (tid <= kImgRows) s_eo[tid * kEoPitch] = make_uint2(0u, 0u);
     // Thread (column group cg, row rr) of an 18 x 14 arrangement: one dword column
     // of the staged tile, rows rr, rr + 14, rr + 28.  252 of the 256 threads take part.
     const int rr = tid / kImgDw, cg = tid - rr * kImgDw;
@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             const int lo9b = min(min(lo3[j + 1], lo3[(j + 4) & 15]), lo3[(j + 7) & 15]);
             best = max(max(best, lo9a), lo9b);
         }
-        s_sc[code - 3 * P] = (uint8_t)(best - 1);   // same pitch, 3 rows up
+        const unsigned srow = (code * 1821u) >> 17;               // code / 72 for code < 40 * 72
+        s_sc[code - 6u * srow - (unsigned)(3 * kScPitch + 3)] = (uint8_t)(best - 1);   // (srow - 3) * 66 + (column - 3)
     }
     // Blur, vertical pass: 7 taps 18 34 49 55 49 34 18 (8.8 fixed point, sum 256) down the
     // columns of the split tile; the result fits 16 bits per pixel.  Item = (column group and
@@ -444,16 +445,17 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         auto survivor = [&](int k) -> unsigned {
             if (k >= n2) return 0u;
             const unsigned code = s_list2[k] & 0xfffu;
-            const unsigned sr = (code * 1725u) >> 17;            // code / 76 for code < 4096
+            const unsigned sr = (code * 1821u) >> 17;            // code / 72 for code < 40 * 72
             const int lx = (int)(code - sr * P) - kImgHalo, ly = (int)sr - kImgHalo;
             const int gx = x0 + lx, gy = y0 + ly;
             if ((unsigned)lx >= (unsigned)kFastTileW || (unsigned)ly >= (unsigned)kFastTileH || gx < edge ||
                 gx >= w - edge || gy < edge || gy >= h - edge)
                 return 0u;
-            const uint8_t* q = s_sc + code - 3 * P;
+            const uint8_t* q = s_sc + (code - 6u * sr - (unsigned)(3 * kScPitch + 3));
+            constexpr int S = kScPitch;
             // all nine reads first: one LDS round trip instead of a chain of eight
             const int s = q[0];
-            const int n0 = q[-1], n1 = q[1], n2_ = q[-P - 1], n3 = q[-P], n4 = q[-P + 1], n5 = q[P - 1], n6 = q[P], n7 = q[P + 1];
+            const int n0 = q[-1], n1 = q[1], n2_ = q[-S - 1], n3 = q[-S], n4 = q[-S + 1], n5 = q[S - 1], n6 = q[S], n7 = q[S + 1];
             const int top = max(max(max(n0, n1), max(n2_, n3)), max(max(n4, n5), max(n6, n7)));
             return (s != 0 && s > top) ? ((unsigned)lx | ((unsigned)ly << 6) | ((unsigned)s << 16)) : 0u;
         };
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
                 if (lane == 0) base = atomicAdd(&s_n[2], (unsigned)__builtin_popcountll(m));
                 base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
                 if (sv) {
-                    atomicAdd(&s_hist[sv >> 16], 1u);
+                    atomicAdd(&a.hist[((size_t)b * a.g.nlevels + l) * 256 + (sv >> 16)], 1u);   // (no copy in LDS: a tile adds a dozen)
                     const unsigned slot = base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
                     if (slot < (unsigned)kTileListCap) s_surv[slot] = sv;
                 }
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         }
     }
     SA_STAMP(10);
-    lds_barrier();   // the survivor list and the histogram are complete
+    lds_barrier();   // the survivor list is complete
     {
         const unsigned ns = min(s_n[2], (unsigned)kTileListCap);
         const size_t gt = (size_t)b * a.g.total_tiles + ftile;
@@ -527,8 +529,6 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         uint32_t* out = a.tilelist + gt * kTileListCap;
         for (unsigned k = tid; k < ns; k += 256) out[k] = s_surv[k];
     }
-    const unsigned hv = s_hist[tid];
-    if (hv) atomicAdd(&a.hist[((size_t)b * a.g.nlevels + l) * 256 + tid], hv);
     SA_STAMP(15);
     SA_STAMP_PRINT;
 }
