@@ -485,7 +485,6 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
                 if (lane == 0) base = atomicAdd(&s_n[2], (unsigned)__builtin_popcountll(m));
                 base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
                 if (sv) {
-                    atomicAdd(&a.hist[((size_t)b * a.g.nlevels + l) * 256 + (sv >> 16)], 1u);   // (no copy in LDS: a tile adds a dozen)
                     const unsigned slot = base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
                     if (slot < (unsigned)kTileListCap) s_surv[slot] = sv;
                 }
@@ -527,7 +526,15 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         const size_t gt = (size_t)b * a.g.total_tiles + ftile;
         if (tid == 0) a.tilecount[gt] = ns;
         uint32_t* out = a.tilelist + gt * kTileListCap;
-        for (unsigned k = tid; k < ns; k += 256) out[k] = s_surv[k];
+        // the level's score histogram takes the survivors directly (no copy in LDS: a tile adds a dozen), and
+        // last of all: atomics on a few hundred hot addresses are slow, and what a wave sends to memory
+        // after them queues behind them
+        unsigned* hist = a.hist + ((size_t)b * a.g.nlevels + l) * 256;
+        for (unsigned k = tid; k < ns; k += 256) {
+            const uint32_t sv = s_surv[k];
+            out[k] = sv;
+            atomicAdd(&hist[sv >> 16], 1u);
+        }
     }
     SA_STAMP(15);
     SA_STAMP_PRINT;
