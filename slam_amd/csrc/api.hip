@@ -194,6 +194,8 @@ static int build_geometry_of(const slam_amd_orb_params& p, int width, int height
     }
     // (the descriptor kernel's 64-byte-wide fetches may run up to three tiles past the last one it needs)
     g.frame_bytes = (off + 3u * 128u + 255u) & ~255u;
+    // long survivor lists (large frames) are selected by 8 workgroups per level, each with a band of tile rows
+    g.bands = g.lv[0].tiles_x * div_up(g.lv[0].h, kFastTileH) > 1024 ? 8 : 1;
     g.total_rows = rows;
     g.total_tiles = tiles;
     return SLAM_AMD_OK;
@@ -435,7 +437,7 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
     if ((rc = ex->pyr.reserve(B * g.frame_bytes))) return fail(rc);
     if ((rc = ex->blur.reserve(B * g.frame_bytes))) return fail(rc);
     // (padded to 256 bytes: the per-call fill is rounded up to whole 256-byte blocks)
-    if ((rc = ex->hist.reserve(((B * (size_t)g.nlevels * 256 * sizeof(unsigned)) + 255) & ~(size_t)255))) return fail(rc);
+    if ((rc = ex->hist.reserve(((B * (size_t)g.nlevels * g.bands * 256 * sizeof(unsigned)) + 255) & ~(size_t)255))) return fail(rc);
     if ((rc = ex->tilecount.reserve(B * (size_t)g.total_tiles * sizeof(unsigned)))) return fail(rc);
     if ((rc = ex->tilelist.reserve(B * (size_t)g.total_tiles * kTileListCap * sizeof(uint32_t)))) return fail(rc);
     if ((rc = ex->sel.reserve(B * sizeof(FrameSelect)))) return fail(rc);
@@ -445,10 +447,11 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
         std::vector<uint32_t> td((size_t)g.total_tiles);
         for (int l = 0; l < g.nlevels; l++) {
             const int nty = div_up(g.lv[l].h, kFastTileH);
-            if (g.lv[l].tiles_x > 0xfff || nty > 0xffff) return fail((set_error("level too large for the tile table"), SLAM_AMD_ERR_ARG));
+            if (g.lv[l].tiles_x > 0xfff || nty > 0xfff) return fail((set_error("level too large for the tile table"), SLAM_AMD_ERR_ARG));
             for (int ty = 0; ty < nty; ty++)
                 for (int tx = 0; tx < g.lv[l].tiles_x; tx++)
-                    td[(size_t)g.lv[l].tile_base + (size_t)ty * g.lv[l].tiles_x + tx] = (uint32_t)l | ((uint32_t)tx << 4) | ((uint32_t)ty << 16);
+                    td[(size_t)g.lv[l].tile_base + (size_t)ty * g.lv[l].tiles_x + tx] = (uint32_t)l | ((uint32_t)tx << 4) | ((uint32_t)ty << 16) |
+                                                                                               ((uint32_t)(ty * g.bands / nty) << 28);
         }
         if ((rc = ex->tiledesc.reserve(td.size() * sizeof(uint32_t)))) return fail(rc);
         if (hipMemcpy(ex->tiledesc.p, td.data(), td.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {

@@ -49,6 +49,10 @@ __host__ __device__ inline unsigned blur_tiled_offset(unsigned pitch, unsigned x
     return (((y >> 3) * (pitch >> 4) + (x >> 4)) << 7) + ((y & 7u) << 4) + (x & 15u);
 }
 
+// Tile rows [first, last) of band k of a level with nty tile rows cut into `bands` bands: the rows ty with
+// ty * bands / nty == k.
+__host__ __device__ inline int band_first_tile_row(int k, int nty, int bands) { return (k * nty + bands - 1) / bands; }
+
 struct PyrGeom {
     int nlevels;
     int edge;           // edge threshold
@@ -56,6 +60,7 @@ struct PyrGeom {
     int total_rows;     // sum of level heights
     int total_tiles;    // FAST tiles per frame
     unsigned frame_bytes;  // bytes of one frame's pyramid (and survivor map)
+    int bands;          // horizontal bands a level is cut into for the selection (score histograms per band): 1, or 8 for large frames
     LevelGeom lv[kMaxLevels];
 };
 

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     }
     if (ftile >= a.g.total_tiles) return;
     const uint32_t td = a.tiledesc[ftile];
-    const int l = (int)(td & 15u), txi = (int)((td >> 4) & 0xfffu), tyi = (int)(td >> 16);
+    const int l = (int)(td & 15u), txi = (int)((td >> 4) & 0xfffu), tyi = (int)((td >> 16) & 0xfffu), band = (int)(td >> 28);
     const LevelGeom& L = a.g.lv[l];
     const int x0 = txi * kFastTileW, y0 = tyi * kFastTileH;
     const int w = L.w, h = L.h;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         // the level's score histogram takes the survivors directly (no copy in LDS: a tile adds a dozen), and
         // last of all: atomics on a few hundred hot addresses are slow, and what a wave sends to memory
         // after them queues behind them
-        unsigned* hist = a.hist + ((size_t)b * a.g.nlevels + l) * 256;
+        unsigned* hist = a.hist + (((size_t)b * a.g.nlevels + l) * a.g.bands + band) * 256;
         for (unsigned k = tid; k < ns; k += 256) {
             const uint32_t sv = s_surv[k];
             out[k] = sv;
@@ -571,11 +571,16 @@ constexpr int kQtCap = 8192;          // survivors of one level the quadtree ker
 // 4 lane + 3, suffix sums over the bins).  With the quadtree option a level that holds more
 // survivors than its quota (and no more than the quadtree kernel sorts) keeps exactly the quota
 // and is marked mode 1: the quadtree kernel writes it, the plain kernel skips it.
-__device__ __forceinline__ void level_selection(const SelectCompactArgs& a, int b, int my_level, int wave, int nwaves, int lane,
+__device__ __forceinline__ void level_selection(const SelectCompactArgs& a, int bands, int b, int my_level, int wave, int nwaves, int lane,
                                                 int* s_cut, int* s_cnt, int* s_mode) {
     for (int l = wave; l <= my_level; l += nwaves) {
-        const unsigned* h = a.hist + ((size_t)b * a.g.nlevels + l) * 256;
-        const unsigned v0 = h[4 * lane], v1 = h[4 * lane + 1], v2 = h[4 * lane + 2], v3 = h[4 * lane + 3];
+        // (the level's histogram is the sum of its bands')
+        const uint4* h = reinterpret_cast<const uint4*>(a.hist + ((size_t)b * a.g.nlevels + l) * bands * 256) + lane;
+        unsigned v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        for (int k = 0; k < bands; k++) {
+            const uint4 q = h[k * 64];
+            v0 += q.x; v1 += q.y; v2 += q.z; v3 += q.w;
+        }
         const unsigned own = v0 + v1 + v2 + v3;
         unsigned suf = own;
 #pragma unroll
@@ -638,8 +643,10 @@ __device__ __forceinline__ unsigned select_block_scan(const unsigned (&c)[R], un
     return before + inc - sum;
 }
 
+// kBanded: the level's tile rows are shared out to a.g.bands workgroups (large frames); else one workgroup per level.
+template <bool kBanded>
 __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompactArgs a) {
-    __shared__ int s_cut[kMaxLevels], s_cnt[kMaxLevels], s_mode[kMaxLevels];
+    __shared__ int s_cut[kMaxLevels], s_cnt[kMaxLevels], s_mode[kMaxLevels], s_bandkept[16];
     __shared__ unsigned s_wave[kSelThreads / 64];
     __shared__ unsigned s_pref[kSelPrefCap + 1];      // tile prefix while gathering, row prefix while ranking
     __shared__ __align__(16) unsigned s_key[kSelKeyCap];
@@ -649,8 +656,12 @@ __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompa
     // Workgroups go round-robin over the 8 XCDs; the level is rotated by the frame so that every XCD
     // gets all levels (with 8 levels and level = blockIdx % 8, one XCD would get every frame's level 0,
     // the longest lists, and another every frame's top level).
-    const int b = blockIdx.x / a.g.nlevels;
-    const int my_level = (int)((blockIdx.x + (unsigned)b) % (unsigned)a.g.nlevels);
+    const int bands = kBanded ? a.g.bands : 1;
+    const int per_frame = a.g.nlevels * bands;
+    const int b = blockIdx.x / per_frame;
+    const int in_frame = (int)blockIdx.x - b * per_frame;
+    const int band = kBanded ? in_frame / a.g.nlevels : 0;          // the band of tile rows this workgroup selects from (one band: the level)
+    const int my_level = (in_frame - band * a.g.nlevels + b) % a.g.nlevels;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if SA_SEL_STAMPS
     unsigned long long sst[6] = {};
@@ -661,7 +672,10 @@ __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompa
 #endif
     const int l = my_level;
     const LevelGeom& L = a.g.lv[l];
-    const int tiles_x = L.tiles_x, ntl = tiles_x * div_up_dev(L.h, kFastTileH);
+    const int tiles_x = L.tiles_x, nty = div_up_dev(L.h, kFastTileH), ntl = tiles_x * nty;
+    // this workgroup's tiles: the tile rows of its band
+    const int row_begin = kBanded ? band_first_tile_row(band, nty, bands) : 0, row_end = kBanded ? band_first_tile_row(band + 1, nty, bands) : nty;
+    const int t_begin = row_begin * tiles_x, t_end = row_end * tiles_x;
     const unsigned* tcount = a.tilecount + (size_t)b * a.g.total_tiles + L.tile_base;
     const uint32_t* tlist = a.tilelist + ((size_t)b * a.g.total_tiles + L.tile_base) * kTileListCap;
     // survivor counts of four tiles per thread; the first chunk's are fetched together with the histograms
@@ -670,12 +684,12 @@ __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompa
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int t = chunk0 + tid * 4 + k;
-            c4[k] = t < ntl ? min(tcount[t], (unsigned)kTileListCap) : 0u;
+            c4[k] = t < t_end ? min(tcount[t], (unsigned)kTileListCap) : 0u;
         }
     };
-    load_counts(0);
+    load_counts(t_begin);
     if (tid == 0) s_n = 0;
-    level_selection(a, b, my_level, wave, kSelThreads / 64, lane, s_cut, s_cnt, s_mode);
+    level_selection(a, bands, b, my_level, wave, kSelThreads / 64, lane, s_cut, s_cnt, s_mode);
     __syncthreads();
 #if SA_SEL_EXP == 2
     if (a.capacity > 0) return;     // experiment: launch + selection
@@ -685,15 +699,28 @@ __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompa
 #endif
 
     const unsigned cut = (unsigned)s_cut[l];
-    const int kept = s_cnt[l];
-    int base = 0;                         // keypoints of the lower levels
-    for (int i = 0; i < l; i++) base += s_cnt[i];
+    int kept = s_cnt[l];
+    int level_base = 0;                   // keypoints of the lower levels
+    for (int i = 0; i < l; i++) level_base += s_cnt[i];
+    int base = level_base;                // ... and of the level's bands above this one
+    if (kBanded) {
+        // kept keypoints of every band up to this one: its histogram from the cut score on (a wave per band)
+        for (int k = wave; k <= band; k += kSelThreads / 64) {
+            const uint4 q = reinterpret_cast<const uint4*>(a.hist + (((size_t)b * a.g.nlevels + l) * bands + k) * 256)[lane];
+            const unsigned s0 = 4u * (unsigned)lane;
+            const int c = (int)((s0 >= cut ? q.x : 0u) + (s0 + 1 >= cut ? q.y : 0u) + (s0 + 2 >= cut ? q.z : 0u) + (s0 + 3 >= cut ? q.w : 0u));
+            const int total = __builtin_amdgcn_readlane(wave_incl_scan(c), 63);
+            if (lane == 0) s_bandkept[k] = total;
+        }
+        __syncthreads();
+        for (int k = 0; k < band; k++) base += s_bandkept[k];
+        kept = s_bandkept[band];
+    }
     slam_amd_keypoint* kp = a.kp + (size_t)b * a.capacity;
     uint32_t* kpxy = a.kpxy + (size_t)b * a.capacity;
     const bool cached = kept <= a.keycap;   // uniform
 
-    auto emit = [&](unsigned key, unsigned sc, int rank) {
-        const int pos = base + rank;
+    auto emit = [&](unsigned key, unsigned sc, int pos) {
         if ((unsigned)pos < (unsigned)a.capacity) {
             const unsigned x = key & 0x3fffu, y = key >> 14;
             slam_amd_keypoint q;
@@ -716,9 +743,9 @@ __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompa
     };
 
     if (kept > 0 && cut < 256 && s_mode[l] == 0) {
-        for (int chunk0 = 0; chunk0 < ntl; chunk0 += kSelTileChunk) {
-            const int nt = min(kSelTileChunk, ntl - chunk0);
-            if (chunk0 > 0) {
+        for (int chunk0 = t_begin; chunk0 < t_end; chunk0 += kSelTileChunk) {
+            const int nt = min(kSelTileChunk, t_end - chunk0);
+            if (chunk0 > t_begin) {
                 __syncthreads();          // s_pref of the chunk before has been read
                 load_counts(chunk0);
             }
@@ -780,7 +807,7 @@ __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompa
                                 rank += ((o >> 16) >= cut) && (key_of(t, o) < key);
                             }
                         }
-                        emit(key, sc, rank);
+                        emit(key, sc, level_base + rank);
                     }
                 }
             }
@@ -791,14 +818,15 @@ __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompa
             sst[3] = __builtin_amdgcn_s_memtime();
 #endif
             const int n = (int)min(s_n, (unsigned)kSelKeyCap);
-            if (L.h <= kSelPrefCap) {
+            const unsigned y_begin = (unsigned)(row_begin * kFastTileH);        // first image row of the band
+            if (min(L.h, row_end * kFastTileH) - (int)y_begin <= kSelPrefCap) {
                 // Rank = keys in the rows above + keys of the same row further left: count the keys of
                 // every row, prefix over the rows, group the keys' x by row, compare within the row.
                 constexpr int R = kSelPrefCap / kSelThreads;
 #pragma unroll
                 for (int k = 0; k < R; k++) s_pref[tid + k * kSelThreads] = 0;
                 __syncthreads();
-                for (int i = tid; i < n; i += kSelThreads) atomicAdd(&s_pref[s_key[i] >> 14], 1u);
+                for (int i = tid; i < n; i += kSelThreads) atomicAdd(&s_pref[(s_key[i] >> 14) - y_begin], 1u);
                 __syncthreads();
                 unsigned r[R];
 #pragma unroll
@@ -813,16 +841,16 @@ __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompa
                 __syncthreads();
                 for (int i = tid; i < n; i += kSelThreads) {
                     const unsigned key = s_key[i];
-                    s_rowx[atomicAdd(&s_pref[key >> 14], 1u)] = (uint16_t)(key & 0x3fffu);   // ... and now one past its last
+                    s_rowx[atomicAdd(&s_pref[(key >> 14) - y_begin], 1u)] = (uint16_t)(key & 0x3fffu);   // ... and now one past its last
                 }
                 __syncthreads();
                 for (int i = tid; i < n; i += kSelThreads) {
                     const unsigned key = s_key[i];
-                    const unsigned y = key >> 14, x = key & 0x3fffu;
+                    const unsigned y = (key >> 14) - y_begin, x = key & 0x3fffu;
                     const unsigned first = y ? s_pref[y - 1] : 0u, last = s_pref[y];
                     int rank = (int)first;
                     for (unsigned j = first; j < last; j++) rank += s_rowx[j] < x;
-                    emit(key, s_score[i], rank);
+                    emit(key, s_score[i], base + rank);
                 }
             } else {
                 // a level with more rows than the prefix array holds: count the smaller keys, all against all
@@ -835,7 +863,7 @@ __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompa
                         const uint4 k4 = *reinterpret_cast<const uint4*>(&s_key[j]);
                         rank += (k4.x < key) + (k4.y < key) + (k4.z < key) + (k4.w < key);
                     }
-                    emit(key, s_score[i], rank);
+                    emit(key, s_score[i], base + rank);
                 }
             }
         }
@@ -847,7 +875,7 @@ __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompa
                (unsigned)s_n, sst[1] - sst[0], sst[2] - sst[1], sst[3] - sst[2], sst[4] - sst[3]);
 #endif
     // the workgroup of the top level has every level's count: it publishes the totals
-    if (threadIdx.x == 0 && my_level == a.g.nlevels - 1) {
+    if (threadIdx.x == 0 && my_level == a.g.nlevels - 1 && band == 0) {
         FrameSelect fs;
         int acc = 0;
         for (int i = 0; i < kMaxLevels; i++) {
@@ -887,7 +915,7 @@ __global__ __launch_bounds__(1024) void quadtree_select_kernel(SelectCompactArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { s_n = 0; s_nc = 0; s_nw = 0; }
     if (tid < 32) s_hc[tid] = 0;
-    level_selection(a, b, l, wave, 16, lane, s_cut, s_cnt, s_mode);
+    level_selection(a, a.g.bands, b, l, wave, 16, lane, s_cut, s_cnt, s_mode);
     __syncthreads();
     if (s_mode[l] != 1) return;
     const LevelGeom& L = a.g.lv[l];
@@ -1188,8 +1216,8 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
     // The first workgroup of every frame leaves the frame's score histograms zeroed for the next call
     // (the selection kernels, which read them, ran before this one).
     if (a.hist_reset && blockIdx.x < (unsigned)a.batch) {
-        uint4* hz = reinterpret_cast<uint4*>(a.hist_reset + (size_t)b * a.g.nlevels * 256);
-        for (int i = lane; i < a.g.nlevels * 64; i += 64) hz[i] = make_uint4(0u, 0u, 0u, 0u);
+        uint4* hz = reinterpret_cast<uint4*>(a.hist_reset + (size_t)b * a.g.nlevels * a.g.bands * 256);
+        for (int i = lane; i < a.g.nlevels * a.g.bands * 64; i += 64) hz[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     const int n = min(a.sel[b].total, a.capacity);
     if (i0 >= n) return;
@@ -1394,7 +1422,8 @@ int launch_fast(const FastArgs& a0, int batch, hipStream_t st) {
 }
 
 int launch_select_compact(const SelectCompactArgs& a, int batch, hipStream_t st) {
-    hipLaunchKernelGGL(select_compact_kernel, dim3(batch * a.g.nlevels), dim3(kSelThreads), 0, st, a);
+    if (a.g.bands > 1) hipLaunchKernelGGL(select_compact_kernel<true>, dim3(batch * a.g.nlevels * a.g.bands), dim3(kSelThreads), 0, st, a);
+    else hipLaunchKernelGGL(select_compact_kernel<false>, dim3(batch * a.g.nlevels), dim3(kSelThreads), 0, st, a);
     SA_HIP(hipGetLastError());
     if (a.quadtree) {
         hipLaunchKernelGGL(quadtree_select_kernel, dim3(batch * a.g.nlevels), dim3(1024), 0, st, a);
