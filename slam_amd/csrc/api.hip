@@ -155,7 +155,13 @@ static void linear_exact_axis(int src, int dst, bool exact_half, int32_t* off, u
 }
 
 static int build_geometry_of(const slam_amd_orb_params& p, int width, int height, PyrGeom& g);
-static int build_geometry(slam_amd_extractor* ex) { return build_geometry_of(ex->params, ex->width, ex->height, ex->g); }
+static int build_geometry(slam_amd_extractor* ex) {
+    const int rc = build_geometry_of(ex->params, ex->width, ex->height, ex->g);
+    // an extractor for one or two frames at a time has too few levels to fill the chip with one selection
+    // workgroup per level: bands from 128 tiles on
+    if (rc == SLAM_AMD_OK && ex->max_batch <= 2 && ex->g.lv[0].tiles_x * div_up(ex->g.lv[0].h, kFastTileH) >= 128) ex->g.bands = 8;
+    return rc;
+}
 
 static int build_geometry_of(const slam_amd_orb_params& p, int width, int height, PyrGeom& g) {
     memset(&g, 0, sizeof g);
