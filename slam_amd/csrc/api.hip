@@ -450,15 +450,30 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
     if ((rc = ex->kpxy.reserve(B * (size_t)max_keypoints * sizeof(uint32_t)))) return fail(rc);
     {
         // the FAST kernel finds its tile by one table read instead of a search over the levels and a division
-        std::vector<uint32_t> td((size_t)g.total_tiles);
+        // The table's order is the order of dispatch.  Without whole frames per XCD, XCD k takes the k-th
+        // eighth of the table: the tile rows of all levels are dealt to eight bins in turn and the bins put
+        // one after the other, so that every eighth holds rows of every level (level 0 first would give one
+        // XCD nothing but full interior tiles and another the small top levels).
+        std::vector<uint32_t> bins[8];
+        int row_number = 0;
         for (int l = 0; l < g.nlevels; l++) {
             const int nty = div_up(g.lv[l].h, kFastTileH);
             if (g.lv[l].tiles_x > 0xfff || nty > 0xfff) return fail((set_error("level too large for the tile table"), SLAM_AMD_ERR_ARG));
-            for (int ty = 0; ty < nty; ty++)
+            for (int ty = 0; ty < nty; ty++, row_number++)
                 for (int tx = 0; tx < g.lv[l].tiles_x; tx++)
-                    td[(size_t)g.lv[l].tile_base + (size_t)ty * g.lv[l].tiles_x + tx] = (uint32_t)l | ((uint32_t)tx << 4) | ((uint32_t)ty << 16) |
-                                                                                               ((uint32_t)(ty * g.bands / nty) << 28);
+                    bins[row_number & 7].push_back((uint32_t)l | ((uint32_t)tx << 4) | ((uint32_t)ty << 16) | ((uint32_t)(ty * g.bands / nty) << 28));
         }
+        // two orders, one after the other: levels, rows, columns (whole frames per XCD: the heavy tiles of a frame
+        // first, the light ones at the end of the launch), then the bins
+        std::vector<uint32_t> td;
+        for (int k = 0; k < 8; k++) td.insert(td.end(), bins[k].begin(), bins[k].end());
+        std::vector<uint32_t> natural(td);
+        std::sort(natural.begin(), natural.end(), [](uint32_t x, uint32_t y) {
+            const uint32_t kx = ((x & 15u) << 24) | (((x >> 16) & 0xfffu) << 12) | ((x >> 4) & 0xfffu);
+            const uint32_t ky = ((y & 15u) << 24) | (((y >> 16) & 0xfffu) << 12) | ((y >> 4) & 0xfffu);
+            return kx < ky;
+        });
+        td.insert(td.begin(), natural.begin(), natural.end());
         if ((rc = ex->tiledesc.reserve(td.size() * sizeof(uint32_t)))) return fail(rc);
         if (hipMemcpy(ex->tiledesc.p, td.data(), td.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipGetLastError();

@@ -180,24 +180,25 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
 
     // Grid: x = tile slot of a frame (a multiple of 8 of them), y = frame.  Workgroups are dealt
     // round-robin over the 8 XCDs, each with its own L2, in x-fastest order, so XCD k sees the slots
-    // with x % 8 == k: it takes the k-th contiguous eighth of every frame's tiles, and tiles that
-    // share halo lines run on the same L2 instead of fetching them once per XCD.  The tile's level
-    // and place come from a table: no search over the levels, no division (scalar instructions
+    // with x % 8 == k: it takes the k-th contiguous eighth of the tile table, whole tile rows of every level
+    // (the table's order deals the rows out), and the tiles of a row, which share halo columns, run on the
+    // same L2 instead of fetching them once per XCD.  The tile's level and place come from that table: no search over the levels, no division (scalar instructions
     // take issue cycles from the vector ones, and every wave of the workgroup repeats them).
-    int b, ftile;
+    int b, slot;      // slot: place in the tile table
     if (a.frames_by_xcd) {
         // a multiple of 8 frames: XCD k takes whole frames (k, k + 8, ...): every XCD gets the same mix of
         // heavy (level 0, interior) and light (top levels, mostly border) tiles, and a frame stays in one L2
         b = (int)blockIdx.y * 8 + (int)(blockIdx.x & 7u);
-        ftile = (int)(blockIdx.x >> 3);
+        slot = (int)(blockIdx.x >> 3);
     } else {
         b = blockIdx.y;
-        ftile = (int)(blockIdx.x & 7u) * a.tiles_eighth + (int)(blockIdx.x >> 3);
+        slot = (int)(blockIdx.x & 7u) * a.tiles_eighth + (int)(blockIdx.x >> 3);
     }
-    if (ftile >= a.g.total_tiles) return;
-    const uint32_t td = a.tiledesc[ftile];
+    if (slot >= a.g.total_tiles) return;
+    const uint32_t td = a.tiledesc[slot];
     const int l = (int)(td & 15u), txi = (int)((td >> 4) & 0xfffu), tyi = (int)((td >> 16) & 0xfffu), band = (int)(td >> 28);
     const LevelGeom& L = a.g.lv[l];
+    const int ftile = L.tile_base + tyi * L.tiles_x + txi;      // the tile's number in the frame (levels, rows, columns)
     const int x0 = txi * kFastTileW, y0 = tyi * kFastTileH;
     const int w = L.w, h = L.h;
     const uint8_t* img;
@@ -1416,6 +1417,7 @@ int launch_fast(const FastArgs& a0, int batch, hipStream_t st) {
     a.frames_by_xcd = SA_FAST_FRAMES_BY_XCD && batch % 8 == 0;
     dim3 grid(a.tiles_eighth * 8, batch);
     if (a.frames_by_xcd) grid = dim3(a.g.total_tiles * 8, batch / 8);
+    else a.tiledesc += a.g.total_tiles;      // the table's second order: tile rows dealt over the eighths
     hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
