@@ -474,8 +474,16 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
             return kx < ky;
         });
         td.insert(td.begin(), natural.begin(), natural.end());
-        if ((rc = ex->tiledesc.reserve(td.size() * sizeof(uint32_t)))) return fail(rc);
-        if (hipMemcpy(ex->tiledesc.p, td.data(), td.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        // an entry carries the tile's number in the frame as well (levels, rows, columns), so that the kernel needs
+        // nothing but the entry to know where its results go
+        std::vector<uint2> td2(td.size());
+        for (size_t i = 0; i < td.size(); i++) {
+            const uint32_t e = td[i];
+            const LevelGeom& L = g.lv[e & 15u];
+            td2[i] = make_uint2(e, (uint32_t)(L.tile_base + (int)((e >> 16) & 0xfffu) * L.tiles_x + (int)((e >> 4) & 0xfffu)));
+        }
+        if ((rc = ex->tiledesc.reserve(td2.size() * sizeof(uint2)))) return fail(rc);
+        if (hipMemcpy(ex->tiledesc.p, td2.data(), td2.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipGetLastError();
             set_error("upload of the tile table failed");
             return fail(SLAM_AMD_ERR_HIP);
@@ -576,7 +584,7 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     fa.img0 = d_images; fa.img0_frame_pitch = frame_pitch; fa.img0_pitch = row_stride; fa.img0_aligned = aligned;
     fa.pyr = ex->pyr.as<uint8_t>(); fa.blur = ex->blur.as<uint8_t>(); fa.hist = ex->hist.as<unsigned>();
     fa.tilecount = ex->tilecount.as<unsigned>(); fa.tilelist = ex->tilelist.as<uint32_t>(); fa.g = g;
-    fa.grid_shift = ex->grid_shift; fa.tiledesc = ex->tiledesc.as<uint32_t>(); fa.tiles_eighth = 0; fa.frames_by_xcd = 0;
+    fa.grid_shift = ex->grid_shift; fa.tiledesc = ex->tiledesc.as<uint2>(); fa.tiles_eighth = 0; fa.frames_by_xcd = 0;
     { ProfScope ps(kStageFast, st); if ((rc = launch_fast(fa, batch, st))) return rc; }
     SelectCompactArgs sc;
     sc.hist = ex->hist.as<unsigned>(); sc.tilecount = ex->tilecount.as<unsigned>(); sc.tilelist = ex->tilelist.as<uint32_t>();

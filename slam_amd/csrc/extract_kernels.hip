@@ -195,10 +195,11 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         slot = (int)(blockIdx.x & 7u) * a.tiles_eighth + (int)(blockIdx.x >> 3);
     }
     if (slot >= a.g.total_tiles) return;
-    const uint32_t td = a.tiledesc[slot];
+    const uint2 tde = a.tiledesc[slot];
+    const uint32_t td = tde.x;
     const int l = (int)(td & 15u), txi = (int)((td >> 4) & 0xfffu), tyi = (int)((td >> 16) & 0xfffu), band = (int)(td >> 28);
     const LevelGeom& L = a.g.lv[l];
-    const int ftile = L.tile_base + tyi * L.tiles_x + txi;      // the tile's number in the frame (levels, rows, columns)
+    const int ftile = (int)tde.y;      // the tile's number in the frame (levels, rows, columns)
     const int x0 = txi * kFastTileW, y0 = tyi * kFastTileH;
     const int w = L.w, h = L.h;
     const uint8_t* img;

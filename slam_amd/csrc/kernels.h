@@ -43,7 +43,7 @@ struct FastArgs {
     unsigned* tilecount;  // [batch][total_tiles] NMS survivors of every FAST tile
     uint32_t* tilelist;   // [batch][total_tiles][kTileListCap] lx | ly << 6 | score << 16, any order
     int grid_shift;       // 0: off; 3, 4, 5: keep the best survivor of every 8, 16, 32 pixel cell
-    const uint32_t* tiledesc;  // [2][total_tiles] level | tile column << 4 | tile row << 16 | band << 28 of every FAST tile, in two orders of a frame (device memory)
+    const uint2* tiledesc;     // [2][total_tiles] {level | tile column << 4 | tile row << 16 | band << 28, tile number} of every FAST tile, in two orders of a frame (device memory)
     int tiles_eighth;     // ceil(total_tiles / 8) (set by the launcher)
     int frames_by_xcd;    // 1: grid = (8 x tile, frame / 8), for a multiple of 8 frames (set by the launcher)
     PyrGeom g;
