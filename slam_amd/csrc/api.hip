@@ -154,12 +154,15 @@ static void linear_exact_axis(int src, int dst, bool exact_half, int32_t* off, u
     }
 }
 
+#ifndef SA_SEL_BANDS
+#define SA_SEL_BANDS 16    // bands of tile rows per level where the selection is banded (at most 16)
+#endif
 static int build_geometry_of(const slam_amd_orb_params& p, int width, int height, PyrGeom& g);
 static int build_geometry(slam_amd_extractor* ex) {
     const int rc = build_geometry_of(ex->params, ex->width, ex->height, ex->g);
     // an extractor for one or two frames at a time has too few levels to fill the chip with one selection
     // workgroup per level: bands from 128 tiles on
-    if (rc == SLAM_AMD_OK && ex->max_batch <= 2 && ex->g.lv[0].tiles_x * div_up(ex->g.lv[0].h, kFastTileH) >= 128) ex->g.bands = 8;
+    if (rc == SLAM_AMD_OK && ex->max_batch <= 2 && ex->g.lv[0].tiles_x * div_up(ex->g.lv[0].h, kFastTileH) >= 128) ex->g.bands = SA_SEL_BANDS;
     return rc;
 }
 
@@ -201,7 +204,7 @@ static int build_geometry_of(const slam_amd_orb_params& p, int width, int height
     // (the descriptor kernel's 64-byte-wide fetches may run up to three tiles past the last one it needs)
     g.frame_bytes = (off + 3u * 128u + 255u) & ~255u;
     // long survivor lists (large frames) are selected by 8 workgroups per level, each with a band of tile rows
-    g.bands = g.lv[0].tiles_x * div_up(g.lv[0].h, kFastTileH) > 1024 ? 8 : 1;
+    g.bands = g.lv[0].tiles_x * div_up(g.lv[0].h, kFastTileH) > 1024 ? SA_SEL_BANDS : 1;
     g.total_rows = rows;
     g.total_tiles = tiles;
     return SLAM_AMD_OK;

@@ -1215,11 +1215,13 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
     const int b = blockIdx.x % a.batch;
     const int i0 = (blockIdx.x / a.batch) * kDescKps;
     const int lane = threadIdx.x;
-    // The first workgroup of every frame leaves the frame's score histograms zeroed for the next call
+    // The workgroups of a frame leave the frame's score histograms zeroed for the next call, one histogram
+    // (1 KB) each, the first workgroups taking a second one where there are more histograms than workgroups
     // (the selection kernels, which read them, ran before this one).
-    if (a.hist_reset && blockIdx.x < (unsigned)a.batch) {
+    if (a.hist_reset) {
+        const int wg = (int)(blockIdx.x / (unsigned)a.batch), wgs = (int)(gridDim.x / (unsigned)a.batch);
         uint4* hz = reinterpret_cast<uint4*>(a.hist_reset + (size_t)b * a.g.nlevels * a.g.bands * 256);
-        for (int i = lane; i < a.g.nlevels * a.g.bands * 64; i += 64) hz[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int h = wg; h < a.g.nlevels * a.g.bands; h += wgs) hz[h * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
     }
     const int n = min(a.sel[b].total, a.capacity);
     if (i0 >= n) return;

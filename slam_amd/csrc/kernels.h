@@ -75,7 +75,7 @@ struct DescribeArgs {
     const uint32_t* kpxy;
     const int32_t* lanegeom;   // [kMaxLevels][8]: width, height, pitch, offset, scale bits, 0, 0, 0 of every level (device memory)
     uint8_t* desc;       // [batch][capacity][32]
-    unsigned* hist_reset; // if set: the score histograms [batch][nlevels][256]; the selection has read them, this kernel zeroes them for the next call
+    unsigned* hist_reset; // if set: the score histograms [batch][nlevels][bands][256]; the selection has read them, this kernel zeroes them for the next call
     int capacity;
     int batch;
     PyrGeom g;
