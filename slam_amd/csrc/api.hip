@@ -203,7 +203,7 @@ static int build_geometry_of(const slam_amd_orb_params& p, int width, int height
     }
     // (the descriptor kernel's 64-byte-wide fetches may run up to three tiles past the last one it needs)
     g.frame_bytes = (off + 3u * 128u + 255u) & ~255u;
-    // long survivor lists (large frames) are selected by 8 workgroups per level, each with a band of tile rows
+    // long survivor lists (large frames) are selected by several workgroups per level, each with a band of tile rows
     g.bands = g.lv[0].tiles_x * div_up(g.lv[0].h, kFastTileH) > 1024 ? SA_SEL_BANDS : 1;
     g.total_rows = rows;
     g.total_tiles = tiles;

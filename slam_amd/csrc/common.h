@@ -60,7 +60,7 @@ struct PyrGeom {
     int total_rows;     // sum of level heights
     int total_tiles;    // FAST tiles per frame
     unsigned frame_bytes;  // bytes of one frame's pyramid (and survivor map)
-    int bands;          // horizontal bands a level is cut into for the selection (score histograms per band): 1, or 8 for large frames
+    int bands;          // horizontal bands a level is cut into for the selection (score histograms per band): 1, or up to 16 for large or single frames
     LevelGeom lv[kMaxLevels];
 };
 
