@@ -283,7 +283,12 @@ MatchPlan plan_match_mfma(int batch, int nq_bound, int nt_bound, int n_cu, bool 
     MatchPlan p = {0, 0, 1, 0};
     if (nq_bound <= 0 || nt_bound <= 0 || batch <= 0) return p;
     p.qblocks = div_up(nq_bound, kMmQueries);
-    int splits = div_up(n_cu * 6, p.qblocks * batch);
+    // Train rows are split over `splits` workgroups per query block.  Two workgroups fit a CU: a launch whose
+    // query blocks alone fill the chip is not split (every split expands the block's queries again: 64 frames
+    // x 8 blocks measured 55 us unsplit, 56.6 in two, 58.4 in three); a smaller one is split until there are
+    // about three workgroups per CU (one 4K frame, 40 blocks: 38 us in 20 splits, 51 in 12 or 13, 40 in 39).
+    const int wgs = p.qblocks * batch;
+    int splits = wgs >= 2 * n_cu ? 1 : div_up(3 * n_cu, wgs);
     splits = std::max(1, std::min(splits, div_up(nt_bound, 4 * kMmTile)));
     if (second) splits = std::min(splits, kMaxSecondSplits);
     p.chunk = div_up(div_up(nt_bound, splits), kMmTile) * kMmTile;
