@@ -203,11 +203,12 @@ int slam_amd_matcher_set_options(slam_amd_matcher* m, float ratio, int histo_len
  * (queries x train rows >= 2^25), 1 forces the full sweep, 2 forces the cell-sorted path. */
 int slam_amd_matcher_debug_set_window_mode(slam_amd_matcher* m, int mode);
 
-/* Test hook.  With both gates off (with or without the ratio option), distances are formed on the matrix
- * cores (Hamming distance as popcount(a) + popcount(b) - 2 a.b over 0/1 bytes); the result
- * is identical to the popcount kernel's.  mode 0 = matrix cores where they apply (default),
- * 1 = always the popcount kernel. */
-int slam_amd_matcher_debug_set_ungated_mode(slam_amd_matcher* m, int mode);
+/* Test hook.  The full sweep (every query against every train row) forms its distances on the
+ * matrix cores -- Hamming distance as popcount(b) + sum t (1 - 2 b) over bytes, the octave and
+ * window gates applied to the products before the arg-min -- with or without the gates and the
+ * ratio option; the result is identical to the popcount kernel's.  mode 0 = matrix cores
+ * (default), 1 = always the popcount kernel. */
+int slam_amd_matcher_debug_set_sweep_kernel(slam_amd_matcher* m, int mode);
 
 /* Host, blocking.  For every query row (ascending), the train row of least
  * Hamming distance among those that pass the gates:

@@ -32,7 +32,7 @@ EXPORTS = [
     "slam_amd_extractor_debug_blurred_level", "slam_amd_extractor_debug_set_select_cache",
     "slam_amd_matcher_create", "slam_amd_matcher_destroy", "slam_amd_matcher_reserve",
     "slam_amd_matcher_set_options", "slam_amd_matcher_debug_set_window_mode",
-    "slam_amd_matcher_debug_set_ungated_mode",
+    "slam_amd_matcher_debug_set_sweep_kernel",
     "slam_amd_frame_match", "slam_amd_frame_match_async", "slam_amd_frame_match_noalloc_async",
     "slam_amd_frame_match_batch_async",
     "slam_amd_frame_match_chain_async",
@@ -86,7 +86,7 @@ def lib():
         l.slam_amd_extract_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         l.slam_amd_matcher_set_options.argtypes = [C.c_void_p, C.c_float, C.c_int]
         l.slam_amd_matcher_debug_set_window_mode.argtypes = [C.c_void_p, C.c_int]
-        l.slam_amd_matcher_debug_set_ungated_mode.argtypes = [C.c_void_p, C.c_int]
+        l.slam_amd_matcher_debug_set_sweep_kernel.argtypes = [C.c_void_p, C.c_int]
         l.slam_amd_extract_batch_async.argtypes = [
             C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
             C.c_void_p, C.c_int, C.c_void_p]
@@ -442,8 +442,8 @@ class Matcher:
     def debug_set_window_mode(self, mode):
         check(lib().slam_amd_matcher_debug_set_window_mode(self._h, mode))
 
-    def debug_set_ungated_mode(self, mode):
-        check(lib().slam_amd_matcher_debug_set_ungated_mode(self._h, mode))
+    def debug_set_sweep_kernel(self, mode):
+        check(lib().slam_amd_matcher_debug_set_sweep_kernel(self._h, mode))
 
     def set_options(self, ratio=0.0, histo_length=0):
         """Ratio test and rotation-consistency filter (neither is in the reference; 0 = off)."""

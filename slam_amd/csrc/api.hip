@@ -747,7 +747,7 @@ struct slam_amd_matcher {
                                        // fails half way leaves this false and the next one fills the whole buffer
     unsigned char* static_scratch = nullptr;  // this device's copy of the file-scope scratch array (no-alloc entry point)
     int window_mode = 0;               // 0: choose by size, 1: always the full sweep, 2: always cell-sorted
-    int ungated_mode = 0;              // 0: matrix-core kernel when no gate and no ratio test is on, 1: always the VALU kernel
+    int sweep_kernel = 0;              // full sweep: 0 = matrix-core kernel (gates and ratio option included), 1 = VALU popcount kernel
     float ratio = 0.f;                 // options beyond the reference, both off by default
     int histo_length = 0;
     DevBuf h_d1, h_k1, h_d2, h_k2, h_ids, h_xy, h_out, h_n, h_aux;  // host-call staging
@@ -861,9 +861,9 @@ extern "C" int slam_amd_matcher_debug_set_window_mode(slam_amd_matcher* m, int m
     return SLAM_AMD_OK;
 }
 
-extern "C" int slam_amd_matcher_debug_set_ungated_mode(slam_amd_matcher* m, int mode) {
+extern "C" int slam_amd_matcher_debug_set_sweep_kernel(slam_amd_matcher* m, int mode) {
     if (!m || mode < 0 || mode > 1) SA_FAIL(SLAM_AMD_ERR_ARG, "mode must be 0 or 1");
-    m->ungated_mode = mode;
+    m->sweep_kernel = mode;
     return SLAM_AMD_OK;
 }
 
@@ -910,8 +910,8 @@ static int match_common(slam_amd_matcher* m, int batch,
     bool windowed = area > 0.f && area <= 3.0e38f && nq > 0 && n2 > 0;
     if (m->window_mode == 1 || no_alloc || chain) windowed = false;   // the full sweep needs no reordered copies
     else if (m->window_mode == 0) windowed = windowed && (long long)nq * n2 >= (1LL << 25);
-    // both gates off: distances on the matrix cores (second-best keys included)
-    const bool use_mfma = !gated && m->ungated_mode == 0;
+    // full sweep: distances on the matrix cores (gates and second-best keys included)
+    const bool use_mfma = m->sweep_kernel == 0;
     MatchPlan plan = use_mfma ? plan_match_mfma(batch, nq, n2, m->n_cu, second) : plan_match(batch, nq, n2, m->n_cu, second);
     if (windowed) plan.splits = window_splits(batch, nq, n2, m->n_cu);
     int rc;
@@ -1137,7 +1137,7 @@ extern "C" int slam_amd_match_pairs_async(slam_amd_matcher* m,
     a.area = area; a.max_level = max_level; a.dmax = dmax_of(max_dist);
     a.pairs = d_pairs; a.n_per = n_per; a.pair_out = d_out;
     ProfScope ps(kStageMatchPairs, reinterpret_cast<hipStream_t>(stream));
-    if (!gated && m->ungated_mode == 0) return launch_match_pairs_mfma(a, n_pairs, reinterpret_cast<hipStream_t>(stream));
+    if (m->sweep_kernel == 0) return launch_match_pairs_mfma(a, n_pairs, reinterpret_cast<hipStream_t>(stream));
     return launch_match_pairs(a, n_pairs, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -20,13 +20,45 @@ def _sets(nq, nt, seed):
     return d1, k1, d2, k2
 
 
+@pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("area,max_level", [(-1.0, -1), (-1.0, 4), (50.0, 4), (50.0, -1), (-1.0, 3)])
-def test_match_gated_vs_oracle(oracle, capi, area, max_level):
+def test_match_gated_vs_oracle(oracle, capi, area, max_level, kernel):
+    """All five gate combinations of the reference's call sites, full sweep on the matrix cores
+    (kernel 0) and with the popcount kernel (kernel 1)."""
     d1, k1, d2, k2 = _sets(1500, 1700, 11)
     m = capi.Matcher()
+    m.debug_set_sweep_kernel(kernel)
+    m.debug_set_window_mode(1)
     got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=area, max_level=max_level)
     ref = oracle.match_gated(d1, k1, d2, k2, 300.0, area, max_level)
     assert np.array_equal(got, ref)
+    m.close()
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (33, 31), (64, 65), (257, 64), (300, 1000), (513, 4097)])
+def test_matrix_core_gates_ragged_sizes_and_sorted_octaves(oracle, capi, nq, nt):
+    """The gates in the matrix-core kernel: sizes around the 32-row blocks and the 256-query workgroups; octaves
+    sorted as an extractor leaves them (whole blocks above or below max_level take the kernel's short cuts) and
+    random; train rows tied in distance where the nearer one fails a gate."""
+    d1, k1, d2, k2 = _sets(nq, nt, 300 + nq + nt)
+    if nt >= 64:
+        d2[40] = d2[7]                       # equal rows: the lower index wins unless a gate removes it
+        k2["octave"][7] = 7
+        k2["x"][40] = k2["x"][7] + 500.0
+    if nq >= 4:
+        d1[1] = d2[min(7, nt - 1)]
+        k1["octave"][1] = 7                  # high query: row 7 is gated out, row 40 must win
+        d1[2] = d2[min(7, nt - 1)]
+        k1["octave"][2] = 0
+    m = capi.Matcher()
+    m.debug_set_window_mode(1)
+    for sort_octaves in (False, True):
+        if sort_octaves:
+            k1["octave"] = np.sort(k1["octave"]); k2["octave"] = np.sort(k2["octave"])
+        for area, lvl in ((-1.0, 4), (45.0, 4), (45.0, -1), (-1.0, 0), (-1.0, 7), (0.0, -1), (float("inf"), 2)):
+            ref = oracle.match_gated(d1, k1, d2, k2, 300.0, area, lvl)
+            got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=area, max_level=lvl)
+            assert np.array_equal(got, ref), (area, lvl, sort_octaves)
     m.close()
 
 
@@ -157,9 +189,11 @@ def test_match_10000_x_10000_vs_oracle(oracle, capi):
     k1["y"] = k2["y"][src] + rng.normal(0, 25, n).astype(np.float32)
     m = capi.Matcher()
     for area, lvl in ((-1.0, -1), (-1.0, 4), (50.0, 4)):
-        got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=area, max_level=lvl)
         ref = oracle.match_gated_mt(d1, k1, d2, k2, 300.0, area, lvl)
-        assert got.tobytes() == ref.tobytes() and len(got) > 5000, (area, lvl, len(got), len(ref))
+        for mode in (0, 1):                  # by size (cell-sorted where the window is on), then the full sweep
+            m.debug_set_window_mode(mode)
+            got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=area, max_level=lvl)
+            assert got.tobytes() == ref.tobytes() and len(got) > 5000, (area, lvl, mode, len(got), len(ref))
     m.close()
 
 
@@ -190,9 +224,11 @@ def test_matrix_core_match_equals_oracle_and_popcount_kernel(oracle, capi, nq, n
         assert ref[5]["trainIdx"] == 37 and ref[6]["trainIdx"] == 9 and ref[7]["trainIdx"] == 37
     m = capi.Matcher()
     got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=-1.0, max_level=-1)
-    m.debug_set_ungated_mode(1)
+    m.debug_set_sweep_kernel(1)
     got_valu = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=-1.0, max_level=-1)
-    m.debug_set_ungated_mode(0)
+    m.debug_set_sweep_kernel(0)
+    got_lvl = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=-1.0, max_level=2)
+    assert np.array_equal(got_lvl, oracle.match_gated(d1, k1, d2, k2, 300.0, -1.0, 2))
     ids = np.arange(nq - 1, -1, -2, dtype=np.int32)
     got_ids = m.frame_match(d1, k1, d2, k2, ids=ids, max_dist=60.0, area=-1.0, max_level=-1)
     ref_ids = oracle.frame_match(d1, k1, d2, k2, ids, 60.0, -1.0, -1)
