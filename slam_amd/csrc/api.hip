@@ -892,6 +892,7 @@ static int match_common(slam_amd_matcher* m, int batch,
     if (!m || !d_out || !d_n_out) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
     if (n1 < 0 || n2 < 0 || n_ids < 0 || batch <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "negative size");
     if (n2 >= (1 << 20)) SA_FAIL(SLAM_AMD_ERR_ARG, "train set larger than 2^20 - 1 rows");
+    if (area != area) area = -2.f;      // a NaN window passes no pair, like any negative one other than -1 (= gate off)
     const bool gated = (area != -1.f) || (max_level != -1);
     if (ids && n_ids == 0) ids = nullptr;
     if ((n1 > 0 && !d1) || (n2 > 0 && !d2)) SA_FAIL(SLAM_AMD_ERR_ARG, "null descriptor pointer");
@@ -1125,6 +1126,7 @@ extern "C" int slam_amd_match_pairs_async(slam_amd_matcher* m,
     if (!m || !d_desc || !d_pairs || !d_out) SA_FAIL(SLAM_AMD_ERR_ARG, "null argument");
     if (n_keyframes <= 0 || n_per <= 0 || n_pairs < 0) SA_FAIL(SLAM_AMD_ERR_ARG, "bad size");
     if (n_per > 65535) SA_FAIL(SLAM_AMD_ERR_ARG, "n_per exceeds 65535 (16-bit train index in the result)");
+    if (area != area) area = -2.f;      // as in match_common
     const bool gated = (area != -1.f) || (max_level != -1);
     if (gated && !d_kp) SA_FAIL(SLAM_AMD_ERR_ARG, "keypoints are required when a gate is on");
     if (reinterpret_cast<uintptr_t>(d_desc) & 15) SA_FAIL(SLAM_AMD_ERR_ARG, "d_desc must be 16-byte aligned");

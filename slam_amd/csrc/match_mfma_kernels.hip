@@ -3,21 +3,25 @@
 // All-pairs Hamming distance is a matrix product: with the 256 descriptor bits of a train row
 // as a 0/1 vector t and those of a query as b,
 //     H(t, b) = popcount(b) + sum_i t_i (1 - 2 b_i)
-// v_mfma_i32_32x32x32_i8 forms the sum for a 32 x 32 block of (train, query) pairs in eight
-// steps of 32 bits: the train bits are expanded to bytes {0, 1}, the query bits to bytes
-// {+32 (bit clear), -32 (bit set)}.  The first product of a block takes a constant accumulator
-// operand, 32 * 256 + (row of the train inside its block of 32), so that an accumulator ends as
-//     32 (H - popcount(b) + 256) + row  >= 0:
-// the order of (distance, train index) inside the block, and the arg-min over a block is a plain
-// unsigned minimum over accumulators.  Across blocks the running best is the minimum of
-// (H - popcount(b) + 256) << 20 | train index, rebuilt from the block's minimum with three
-// instructions.  popcount(b) is constant per query and is added after the arg-min.  Ties go to
-// the lowest train index, as in the popcount kernel.
+// v_mfma_scale_f32_32x32x64_f8f6f4 on 4-bit operands (FP4, E2M1) forms the sum for a 32 x 32 block of
+// (train, query) pairs in four products of 64 bits -- twice the rate of the 8-bit integer product, and
+// half the operand bytes.  A train bit becomes the nibble 0b0001 (0.5) or 0, a query bit 0b0010 (+1) where
+// it is clear and 0b1010 (-1) where it is set, and the query side carries the block scale 2^6, so every
+// term is 0 or +-32 and the fp32 accumulation is exact (integers far below 2^24).  The first product of a
+// block takes a constant accumulator operand, 2^15 + 32 * 256 + (row of the train inside its block of 32),
+// so that an accumulator ends as the float
+//     2^15 + 32 Hb + row,   Hb = H - popcount(b) + 256 in [0, 512]:
+// all of them in [2^15, 2^16), where a float's bit pattern is 0x47000000 + (32 Hb + row) << 8.  The bit
+// patterns therefore order like (distance, train row inside the block), the arg-min over a block is a plain
+// unsigned minimum over accumulators, and the fields are read off the winner's bits without a conversion.
+// Across blocks, visited in ascending order, a block's minimum replaces the running one only if its Hb is
+// smaller.  popcount(b) is constant per query and is added after the arg-min.  Ties go to the lowest train
+// index, as in the popcount kernel.
 //
 // Gates (_filterMatches of the reference: /root/reference/src/frame/matcher.cpp:144-157) act on
-// the accumulators before the minimum: a pair that fails sets bit 15 of its accumulator, which
-// puts its distance above 256 -- it loses against every pair that passes, and a query whose best
-// pair carries the bit has no match.  The octave gate costs nothing for a block of train rows
+// the accumulators before the minimum: a pair that fails gets the sign bit of its accumulator set (as an
+// unsigned pattern above every accumulator of a pair that passes), which puts its distance above 256 -- it loses against every pair that passes, and a query
+// whose best pair carries the mark has no match.  The octave gate costs nothing for a block of train rows
 // without a row above max_level or a block of queries without one (a 32-bit mask per block of
 // train rows, tested by the whole wave); the window gate compares positions per pair (train
 // positions of the block from LDS, the query's own in a register).  Rows past the end of the
@@ -26,12 +30,14 @@
 // Layout of one product: train rows are the M side (A operand), queries the N side (B operand).
 // An accumulator register of lane l belongs to query l & 31, so the arg-min over the train rows
 // runs inside the lane; the two lane halves hold different train rows and are merged once at
-// the end.  Queries stay in registers for the whole kernel (expanded once); train tiles of 64
-// rows are expanded cooperatively into LDS, double buffered.
+// the end.  Queries stay in registers for the whole kernel (expanded once); train tiles of 128
+// rows are expanded cooperatively into LDS, three buffers deep.
 //
-// The K order inside a step does not matter as long as both operands use the same one: lane
-// half h of either operand supplies the bits of bytes 16h .. 16h + 15 of its descriptor (expand32).
+// The K order inside a product does not matter as long as both operands use the same one: product s
+// takes descriptor dwords 2s and 2s + 1, lane half h of either operand supplies dword 2s + h as the 32
+// nibbles of expand_train / expand_query.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -39,39 +45,55 @@
 namespace sa {
 
 constexpr int kMmBlock = 256;                 // 4 waves
-#ifndef SA_MM_NB
-#define SA_MM_NB 2
-#endif
-constexpr int kMmNB = SA_MM_NB;               // query blocks of 32 per wave
+constexpr int kMmNB = 2;                      // query blocks of 32 per wave
 constexpr int kMmQueries = 4 * kMmNB * 32;    // queries per workgroup
 constexpr int kMmSub = 32;                    // train rows of one product
-constexpr int kMmTile = 64;                   // train rows per LDS tile (two products)
-constexpr int kMmSteps = 8;                   // steps of 32 descriptor bits per lane half
+#ifndef SA_MM_BT
+#define SA_MM_BT 4
+#endif
+constexpr int kMmBT = SA_MM_BT;               // blocks of 32 train rows per LDS tile (even)
+constexpr int kMmTile = kMmSub * kMmBT;       // train rows per LDS tile
+constexpr int kMmSteps = 4;                   // products per block: 64 descriptor bits each, 32 per lane half
 constexpr int kMmSubU4 = kMmSteps * 64;       // uint4 slots of one expanded block of 32 rows: [step][half][row]
 constexpr unsigned kMmNoMatch = 0xffffffffu;
 constexpr int kMmIdxBits = 20;
 constexpr int kMmBlockBits = 15;              // kMmIdxBits minus the 5 row bits an accumulator carries
-constexpr int kMmBias = 32 * 256;             // keeps an accumulator non-negative: H - popcount(b) >= -256
-constexpr unsigned kMmFail = 1u << 15;        // set in the accumulator of a pair that fails a gate (distance + 1024)
+constexpr int kMmBias = 32768 + 32 * 256;     // accumulators in [2^15, 2^16): one binade, H - popcount(b) >= -256
+constexpr unsigned kMmBinade = 0x47000000u;   // bit pattern of 32768.f; an accumulator's is kMmBinade + (32 Hb + row) << 8
+constexpr unsigned kMmRowBits = 31u << 8;
+constexpr unsigned kMmFail = 1u << 31;        // set in the bits of the accumulator of a pair that fails a gate: as unsigned patterns, above all that pass
+constexpr int kMmScaleOne = 127, kMmScale64 = 133;   // E8M0 block scales 2^0 and 2^6
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
-// One descriptor dword -> the 32 bytes of its bits, as two operand slices of 16 bytes (steps 2d and 2d + 1 of
-// the lane half that owns dword d): byte j of output dword k is bit k + 8 j of the input, which takes one
-// shift and one mask per output dword.  A byte is `zero` where the bit is clear and `zero + scale` (mod 256)
-// where it is set.  Both operands use this order, so the products pair equal bits.
-template <unsigned SCALE, unsigned ZERO>
-__device__ __forceinline__ void expand32(unsigned w, v4i& lo, v4i& hi) {
-    unsigned o[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        o[k] = (w >> k) & 0x01010101u;
-        if (SCALE != 1u || ZERO != 0u) o[k] = o[k] * SCALE + ZERO;
-    }
-    lo.x = (int)o[0]; lo.y = (int)o[1]; lo.z = (int)o[2]; lo.w = (int)o[3];
-    hi.x = (int)o[4]; hi.y = (int)o[5]; hi.z = (int)o[6]; hi.w = (int)o[7];
+// One descriptor dword -> the 32 nibbles of its bits (one product's operand of one lane): nibble j of output
+// dword k is bit k + 4 j of the input, one shift and one mask per output dword.  Train: 0b0001 = 0.5 where the
+// bit is set; query: 0b0010 = +1 where it is clear, 0b1010 = -1 where it is set.
+__device__ __forceinline__ uint4 expand_train(unsigned w) {
+    return make_uint4(w & 0x11111111u, (w >> 1) & 0x11111111u, (w >> 2) & 0x11111111u, (w >> 3) & 0x11111111u);
 }
+__device__ __forceinline__ v4i expand_query(unsigned w) {
+    v4i r;
+    r.x = (int)(0x22222222u | ((w & 0x11111111u) << 3));
+    r.y = (int)(0x22222222u | (((w >> 1) & 0x11111111u) << 3));
+    r.z = (int)(0x22222222u | (((w >> 2) & 0x11111111u) << 3));
+    r.w = (int)(0x22222222u | (((w >> 3) & 0x11111111u) << 3));
+    return r;
+}
+
+// train (A, 0 / 0.5) x query (B, +-1, block scale 2^6), FP4 both: acc + 32 * (set train bits over clear query bits
+// minus set train bits over set query bits)
+__device__ __forceinline__ v16f product(const v4i& ta, const v4i& qb, const v16f& acc, int scale_a, int scale_b) {
+    const v8i A = {ta.x, ta.y, ta.z, ta.w, 0, 0, 0, 0}, B = {qb.x, qb.y, qb.z, qb.w, 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, 4, 4, 0, scale_a, 0, scale_b);
+}
+
+// bit pattern of accumulator i (the element is copied first: a bit cast of a vector element in place reads element 0)
+__device__ __forceinline__ unsigned acc_bits(const v16f& acc, int i) { const float f = acc[i]; return __float_as_uint(f); }
+__device__ __forceinline__ void acc_fail(v16f& acc, int i) { const float f = acc[i]; acc[i] = __uint_as_float(__float_as_uint(f) | kMmFail); }
 
 #ifdef SA_MM_STAMPS
 // Diagnostic build only: per wave, the shader clock at four points of the kernel, the hardware id and the real-time clock.
@@ -89,11 +111,12 @@ __device__ __forceinline__ constexpr int acc_row(int i, int h) { return 8 * (i >
 // AREA / LEVEL: the window and octave gates.
 template <bool PAIRS, bool SECOND, bool AREA, bool LEVEL>
 __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
-    __shared__ uint4 s_tile[3][2 * kMmSubU4];
-    // per tile, four deep: one keypoint dword per (staging dword index, row) -- x, y, octave, octave ... -- and per
-    // block of 32 rows the mask of the rows with octave > max_level (as wave 1 sees it; the other slots are unused)
-    __shared__ __align__(16) unsigned s_meta[(AREA || LEVEL) ? 4 : 1][(AREA || LEVEL) ? 8 : 1][(AREA || LEVEL) ? kMmTile : 4];
-    __shared__ unsigned s_high[4][2][4];
+    __shared__ uint4 s_tile[3][kMmBT * kMmSubU4];
+    // per tile, four deep: the rows' positions (x, then y) and per block of 32 rows the mask of the rows with
+    // octave > max_level
+    __shared__ __align__(16) unsigned s_meta[AREA ? 4 : 1][2][AREA ? kMmTile : 4];
+    __shared__ unsigned s_high[4][kMmBT];
+    __shared__ __align__(16) float s_box[AREA ? 4 : 1][kMmBT][4];      // per block of 32 rows: x min, x max, y min, y max
 
     int prob, qblock, split;
     size_t qbase, tbase;
@@ -125,7 +148,10 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
     }
     const int t_begin = split * a.chunk;      // a multiple of kMmTile
     const int t_end = PAIRS ? nt : min(nt, t_begin + a.chunk);
-    if (qblock * kMmQueries >= nq || t_begin >= t_end) return;
+    // (nq and t_end come from counts in device memory; the exit that needs them stands behind the first loads of
+    // train rows, which are clamped to the host's row bound instead, so that one memory round trip serves both)
+    const int nt_bound = PAIRS ? a.n_per : a.n2;
+    if (nt_bound <= 0) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -137,112 +163,174 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
     }
 #endif
 
-    // ---- queries of this wave: expanded once, bytes +32 / -32 ----
-    v4i bq[kMmNB][8];
-    int pq[kMmNB];      // popcount of the whole query descriptor
-    int qidx[kMmNB];
-    float qx[kMmNB], qy[kMmNB];
-    bool qhigh[kMmNB];
-    bool any_qhigh[kMmNB];
-#pragma unroll
-    for (int b = 0; b < kMmNB; b++) {
-        const int qi = qblock * kMmQueries + (wave * kMmNB + b) * 32 + r;
-        qidx[b] = qi;
-        uint4 q = make_uint4(0u, 0u, 0u, 0u);
-        qx[b] = qy[b] = 0.f;
-        qhigh[b] = false;
-        if (qi < nq) {
-            const size_t row = qs.base + (size_t)((!PAIRS && a.ids) ? a.ids[qi] : qi);
-            q = reinterpret_cast<const uint4*>(qs.desc + row * 32)[h];
-            if (AREA) {
-                if (!PAIRS && a.q_xy) {
-                    qx[b] = a.q_xy[2 * (qbase + qi)];
-                    qy[b] = a.q_xy[2 * (qbase + qi) + 1];
-                } else {
-                    qx[b] = qs.kp[row].x;
-                    qy[b] = qs.kp[row].y;
-                }
-            }
-            if (LEVEL) qhigh[b] = qs.kp[row].octave > a.max_level;
-        }
-        any_qhigh[b] = LEVEL && __ballot(qhigh[b]) != 0ull;
-        const unsigned w[4] = {q.x, q.y, q.z, q.w};
-        int pc = 0;
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            pc += __builtin_popcount(w[d]);
-            expand32<0xc0u, 0x20202020u>(w[d], bq[b][2 * d], bq[b][2 * d + 1]);
-        }
-        pq[b] = pc + __shfl_xor(pc, 32, 64);
-    }
-    // accumulator operand of a block's first product: the bias and the row an accumulator belongs to
-    v16i c_init;
-#pragma unroll
-    for (int i = 0; i < 16; i++) c_init[i] = kMmBias + acc_row(i, h);
-
-    // ---- train tile staging: thread (d, tr) expands dword d of train rows tr and tr + 32 of a tile.  With a gate on
-    //      it also fetches one dword of either row's keypoint: x (d = 0), y (d = 1) or the octave (d >= 2) ----
+    // ---- train tile staging: thread (d, tr) expands dword d of train rows tr, tr + 32 ... of a tile.  With a gate on,
+    //      wave w also fetches what the gates need of block w: lane l the x (l < 32) or y of row l % 32, and its octave ----
+    static_assert(kMmBT == 4, "one wave per block of a tile stages the block's keypoint data");
     const int sd = tid >> 5, tr = tid & 31;
-    const int sh = sd >> 2, sdd = sd & 3;
     constexpr bool kMeta = AREA || LEVEL;
-    const int meta_dword = sd < 2 ? sd : 5;        // offset of x, y, octave in a keypoint record, in dwords
-    struct Staged { unsigned w[2]; unsigned meta[2]; bool valid[2]; };
-    // (no branches: rows past the end read the set's last row and are zeroed; 32-bit offsets from bases that are
-    // the same in every lane)
+    struct Staged { unsigned w[kMmBT]; unsigned pos, octave, trow; };
+    // (no branches: rows past the bound read the last row below it; rows past the end of the set -- the count in device
+    // memory -- are marked as failed where the set ends inside a tile; 32-bit offsets from bases that are the same in
+    // every lane)
     const uint8_t* const tdesc_base = a.tdesc + tbase * 32;
     const uint8_t* const tkp_base = reinterpret_cast<const uint8_t*>(a.tkp + tbase);
-    const unsigned last_row = (unsigned)(t_end - 1);
+    const unsigned bound_row = (unsigned)(nt_bound - 1);
+    const unsigned my_off = (unsigned)tr * 32u + (unsigned)sd * 4u, bound_off = bound_row * 32u + (unsigned)sd * 4u;
     auto load_row = [&](int t0, int k, Staged& s) {
-        const unsigned t = (unsigned)(t0 + k * kMmSub + tr);
-        s.valid[k] = t <= last_row;
-        const unsigned row = min(t, last_row);
-        s.w[k] = *reinterpret_cast<const unsigned*>(tdesc_base + (row * 32u + (unsigned)sd * 4u));
-        s.meta[k] = kMeta ? *reinterpret_cast<const unsigned*>(tkp_base + (row * (unsigned)sizeof(slam_amd_keypoint) + (unsigned)meta_dword * 4u)) : 0u;
+        s.w[k] = *reinterpret_cast<const unsigned*>(tdesc_base + min(my_off + (unsigned)(t0 + k * kMmSub) * 32u, bound_off));
+    };
+    auto load_meta = [&](int t0, Staged& s) {
+        if (!kMeta) return;
+        const unsigned t = (unsigned)(t0 + wave * kMmSub + r);
+        const unsigned rec = min(t, bound_row) * (unsigned)sizeof(slam_amd_keypoint);
+        s.trow = t;
+        if (AREA) s.pos = *reinterpret_cast<const unsigned*>(tkp_base + (rec + (unsigned)h * 4u));
+        if (LEVEL) s.octave = *reinterpret_cast<const unsigned*>(tkp_base + (rec + 20u));
     };
     auto load_tile = [&](int t0, Staged& s) {
-        load_row(t0, 0, s);
-        load_row(t0, 1, s);
-    };
-    // expanded rows: [block][step][half][row] of 16 bytes; this thread's two slices of block k
-    auto stage_slot = [&](int buf, int k, int hi) { return &s_tile[buf][k * kMmSubU4 + ((2 * sdd + hi) * 2 + sh) * 32 + tr]; };
-    auto stage_meta = [&](int mb, const Staged& s) {
-        if (!kMeta) return;
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            s_meta[mb][sd][k * kMmSub + tr] = s.meta[k];
-            if (LEVEL) {
-                // lanes 0-31 of wave 1 hold the octaves of the block's rows (d = 2)
-                const unsigned long long mask = __ballot(sd == 2 && s.valid[k] && (int)s.meta[k] > a.max_level);
-                s_high[mb][k][wave] = (unsigned)mask;
-            }
+        for (int k = 0; k < kMmBT; k++) load_row(t0, k, s);
+        load_meta(t0, s);
+    };
+    // expanded rows: [block][step][half][row] of 16 bytes; dword d belongs to step d / 2, half d % 2
+    auto stage_slot = [&](int buf, int k) { return &s_tile[buf][k * kMmSubU4 + sd * 32 + tr]; };
+    auto stage_meta = [&](int mb, const Staged& s) {
+        if (AREA) {
+            // a position that is NaN or infinite fails the window with every query: stored as +infinity, and a query's as
+            // -infinity, so that no difference is ever a NaN (the window test takes a maximum, which would drop one)
+            const bool odd = (s.pos & 0x7f800000u) == 0x7f800000u;
+            const unsigned pos = odd ? 0x7f800000u : s.pos;
+            s_meta[mb][h][wave * kMmSub + r] = pos;
+            // the block's box: minimum and maximum over the 32 lanes of either half (x in one, y in the other)
+            float lo = __uint_as_float(pos), hi = lo;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) { lo = fminf(lo, __shfl_xor(lo, d, 64)); hi = fmaxf(hi, __shfl_xor(hi, d, 64)); }
+            s_box[mb][wave][2 * h] = lo;
+            s_box[mb][wave][2 * h + 1] = hi;
+        }
+        if (LEVEL) {
+            // both lane halves hold the block's 32 rows: either half of the ballot is the block's mask
+            const unsigned long long mask = __ballot((int)s.trow < t_end && (int)s.octave > a.max_level);
+            s_high[mb][wave] = (unsigned)mask;
         }
     };
     auto stage_tile = [&](int buf, const Staged& s) {
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            v4i lo, hi;
-            expand32<1u, 0u>(s.valid[k] ? s.w[k] : 0u, lo, hi);
-            *stage_slot(buf, k, 0) = make_uint4((unsigned)lo.x, (unsigned)lo.y, (unsigned)lo.z, (unsigned)lo.w);
-            *stage_slot(buf, k, 1) = make_uint4((unsigned)hi.x, (unsigned)hi.y, (unsigned)hi.z, (unsigned)hi.w);
-        }
+        for (int k = 0; k < kMmBT; k++) *stage_slot(buf, k) = expand_train(s.w[k]);
     };
-    // this lane's operand slice of block k, step s of a buffer
+    // this lane's operand of block k, product s of a buffer
     auto operand = [&](int buf, int k, int s) { return *reinterpret_cast<const v4i*>(&s_tile[buf][k * kMmSubU4 + s * 64 + h * 32 + r]); };
+
+    // the queries and the first three tiles' rows, requested before anything waits for the counts (query rows past
+    // the host's bound repeat the last one below it; rows past the count are dropped at the end)
+    const int nq_bound = PAIRS ? a.n_per : (a.ids ? a.n_ids : a.n1);
+    if (nq_bound <= 0) return;
+    uint4 q0[kMmNB], q1[kMmNB];
+    int qidx[kMmNB];
+    float qx[kMmNB], qy[kMmNB];
+    int qoct[kMmNB];
+#pragma unroll
+    for (int b = 0; b < kMmNB; b++) {
+        const int qi = qblock * kMmQueries + (wave * kMmNB + b) * 32 + r;
+        qidx[b] = qi;
+        const int qc = min(qi, nq_bound - 1);
+        const size_t row = qs.base + (size_t)((!PAIRS && a.ids) ? a.ids[qc] : qc);
+        q0[b] = reinterpret_cast<const uint4*>(qs.desc + row * 32)[0];
+        q1[b] = reinterpret_cast<const uint4*>(qs.desc + row * 32)[1];
+        qx[b] = qy[b] = 0.f;
+        qoct[b] = 0;
+        if (AREA) {
+            if (!PAIRS && a.q_xy) {
+                qx[b] = a.q_xy[2 * (qbase + qc)];
+                qy[b] = a.q_xy[2 * (qbase + qc) + 1];
+            } else {
+                qx[b] = qs.kp[row].x;
+                qy[b] = qs.kp[row].y;
+            }
+        }
+        if (LEVEL) qoct[b] = qs.kp[row].octave;
+    }
+    // (after the queries: a gather through ids waits for every load before it)
+    Staged g, g0, g1;
+    load_tile(t_begin, g0);
+    load_tile(t_begin + kMmTile, g1);
+    load_tile(t_begin + 2 * kMmTile, g);
+    if (qblock * kMmQueries >= nq || t_begin >= t_end) return;
+
+    // ---- queries of this wave: expanded once ----
+    v4i bq[kMmNB][kMmSteps];
+    int pq[kMmNB];      // popcount of the whole query descriptor
+    bool qhigh[kMmNB];
+    bool any_qhigh[kMmNB];
+#pragma unroll
+    for (int b = 0; b < kMmNB; b++) {
+        qhigh[b] = LEVEL && qidx[b] < nq && qoct[b] > a.max_level;
+        if (AREA) {     // see stage_meta
+            if ((__float_as_uint(qx[b]) & 0x7f800000u) == 0x7f800000u) qx[b] = __uint_as_float(0xff800000u);
+            if ((__float_as_uint(qy[b]) & 0x7f800000u) == 0x7f800000u) qy[b] = __uint_as_float(0xff800000u);
+        }
+        any_qhigh[b] = LEVEL && __ballot(qhigh[b]) != 0ull;
+        // dword 2s + h of the descriptor for product s
+        const unsigned w[kMmSteps] = {h ? q0[b].y : q0[b].x, h ? q0[b].w : q0[b].z, h ? q1[b].y : q1[b].x, h ? q1[b].w : q1[b].z};
+        int pc = 0;
+#pragma unroll
+        for (int s = 0; s < kMmSteps; s++) {
+            pc += __builtin_popcount(w[s]);
+            bq[b][s] = expand_query(w[s]);
+        }
+        pq[b] = pc + __shfl_xor(pc, 32, 64);
+    }
+    // bounding box of this wave's queries (both lane halves hold the same 32 per query block): a block of train rows
+    // whose own box lies a window or more away in x or in y cannot pass the window gate with any of them
+    float qbox[4] = {0.f, 0.f, 0.f, 0.f};      // x min, x max, y min, y max
+    if (AREA) {
+        const float inf = __uint_as_float(0x7f800000u);
+        qbox[0] = qbox[2] = inf; qbox[1] = qbox[3] = -inf;
+#pragma unroll
+        for (int b = 0; b < kMmNB; b++)
+            if (qidx[b] < nq) {
+                qbox[0] = fminf(qbox[0], qx[b]); qbox[1] = fmaxf(qbox[1], qx[b]);
+                qbox[2] = fminf(qbox[2], qy[b]); qbox[3] = fmaxf(qbox[3], qy[b]);
+            }
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            qbox[0] = fminf(qbox[0], __shfl_xor(qbox[0], d, 64)); qbox[1] = fmaxf(qbox[1], __shfl_xor(qbox[1], d, 64));
+            qbox[2] = fminf(qbox[2], __shfl_xor(qbox[2], d, 64)); qbox[3] = fmaxf(qbox[3], __shfl_xor(qbox[3], d, 64));
+        }
+    }
+    // accumulator operand of a block's first product: the bias and the row an accumulator belongs to
+    v16f c_init;
+#pragma unroll
+    for (int i = 0; i < 16; i++) c_init[i] = (float)(kMmBias + acc_row(i, h));
+    // block scales of the two operands (byte 0 of a register each)
+    int scale_a = kMmScaleOne, scale_b = kMmScale64;
+    asm volatile("" : "+v"(scale_a), "+v"(scale_b));     // held in registers, not rebuilt per product
 
     unsigned best[kMmNB], second[kMmNB];
 #pragma unroll
     for (int b = 0; b < kMmNB; b++) best[b] = second[b] = kMmNoMatch;
+
     // ---- the arg-min over a block's accumulators, cut into sixteen parts so that it can be issued between the
-    //      products of the next block: parts 0-7 take accumulators 2n and 2n + 1 of both query blocks, parts
-    //      8-11 and 12-15 fold the minimum of query block 0 and 1 (two minima each with SECOND) into the
-    //      running keys: 32 Hb + row  ->  Hb << 20 | block * 32 + row, the order (distance, train index).
-    //      An accumulator is below 2^16. ----
+    //      products of the next block: parts 0-7 take accumulators 2n and 2n + 1 of both query blocks (as bit
+    //      patterns), parts 8-11 and 12-15 fold the minimum of query block 0 and 1 into the running best.
+    //      Without SECOND that is (bit pattern, block number): blocks come in ascending order, so a later block
+    //      wins only with a smaller Hb -- its pattern with all row bits set is still below the running one.
+    //      With SECOND the two smallest accumulators become keys Hb << 20 | block * 32 + row, the order
+    //      (distance, train index), and are merged into the running pair.  A pattern with the failure mark is
+    //      clamped to Hb = 1023 there. ----
     unsigned run_lo[kMmNB], run_hi[kMmNB], key_lo[kMmNB], key_hi[kMmNB];
-    auto argmin_part = [&](const v16i (&acc)[kMmNB], int n, int blockno) {
+    unsigned best_blk[kMmNB];
+#pragma unroll
+    for (int b = 0; b < kMmNB; b++) best_blk[b] = 0u;
+    auto bits_key = [](unsigned bits, int blockno) {
+        const unsigned u = min(bits - kMmBinade, 0x7fffffu);      // Hb << 13 | row << 8
+        return ((u & ~0x1fffu) << 7) + ((u >> 8) & 31u) + (unsigned)blockno;
+    };
+    auto argmin_part = [&](const v16f (&acc)[kMmNB], int n, int blockno) {
         if (n < 8) {
 #pragma unroll
             for (int b = 0; b < kMmNB; b++) {
-                const unsigned x = (unsigned)acc[b][2 * n], y = (unsigned)acc[b][2 * n + 1];
+                const unsigned x = acc_bits(acc[b], 2 * n), y = acc_bits(acc[b], 2 * n + 1);
                 if (SECOND) {
                     // the two smallest so far (run_lo <= run_hi) merged with the sorted pair
                     const unsigned lo = min(x, y), hi = max(x, y);
@@ -258,104 +346,167 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
             return;
         }
         const int b = (n - 8) >> 2, part = (n - 8) & 3;
-        if (part == 0) {
-            key_lo[b] = run_lo[b] & 31u;
-            if (SECOND) key_hi[b] = run_hi[b] & 31u;
-        } else if (part == 1) {
-            key_lo[b] = (unsigned)blockno - key_lo[b] * ((1u << kMmBlockBits) - 1u);
-            if (SECOND) key_hi[b] = (unsigned)blockno - key_hi[b] * ((1u << kMmBlockBits) - 1u);
-        } else if (part == 2) {
-            key_lo[b] += run_lo[b] << kMmBlockBits;
-            if (SECOND) key_hi[b] += run_hi[b] << kMmBlockBits;
-        } else {
-            // best <= second and key_lo < key_hi: the two smallest of the four
-            if (SECOND) second[b] = min(max(best[b], key_lo[b]), min(second[b], key_hi[b]));
-            best[b] = min(best[b], key_lo[b]);
+        if (!SECOND) {
+            if (part == 0) {
+                const bool take = (run_lo[b] | kMmRowBits) < best[b];
+                best[b] = take ? run_lo[b] : best[b];
+                best_blk[b] = take ? (unsigned)blockno : best_blk[b];
+            }
+            return;
         }
+        if (part == 0) key_lo[b] = bits_key(run_lo[b], blockno);
+        else if (part == 1) key_hi[b] = bits_key(run_hi[b], blockno);
+        else if (part == 2) second[b] = min(max(best[b], key_lo[b]), min(second[b], key_hi[b]));   // best <= second, key_lo < key_hi
+        else best[b] = min(best[b], key_lo[b]);
     };
 
-    // ---- gates: mark the accumulators of the pairs that fail.  `rows_left`: rows of the block inside the set ----
-    auto apply_gates = [&](v16i (&acc)[kMmNB], int mb, int k, int rows_left) {
-        if (rows_left < kMmSub) {
+    // ---- gates: mark the accumulators of the pairs that fail ----
+    // rows past the end of the set (`rows_left`: rows of the block inside it)
+    auto gate_tail = [&](v16f (&acc)[kMmNB], int rows_left) {
+        if (rows_left >= kMmSub) return;
 #pragma unroll
-            for (int b = 0; b < kMmNB; b++)
+        for (int b = 0; b < kMmNB; b++)
 #pragma unroll
-                for (int i = 0; i < 16; i++)
-                    if (acc_row(i, h) >= rows_left) acc[b][i] |= (int)kMmFail;
-        }
+            for (int i = 0; i < 16; i++)
+                if (acc_row(i, h) >= rows_left) acc_fail(acc[b], i);
+    };
+    // The octave and window gates of one block, in four parts (part n: accumulators 4n .. 4n + 3 of both query
+    // blocks, the train rows 8n + 4h .. + 3) that go in front of the arg-min parts reading the same accumulators.
+    // Window: with m = max(|dx|, |dy|) >= 0 (or NaN), "not (m < area)" is the sign of (bits(area) - 1) - bits(m)
+    // in integer arithmetic -- float patterns of non-negative values order like integers, a NaN lies above
+    // infinity, a negative area (pattern with the sign bit) fails every pair, as the comparison does.  Octave:
+    // bit `row` of the block's mask of high rows, for queries that are high themselves.  Either sign lands in
+    // the accumulator's sign bit with one and-or.
+    const int area_bits_m1 = (int)__float_as_uint(a.area) - 1;
+    typedef const __attribute__((address_space(3))) v4f* LdsRows;
+    struct BlockGate { unsigned mine[kMmNB]; LdsRows px, py; v4f x4, y4; };
+    // 0: no pair of the block can pass the window (nothing to mark, nothing to fold); 1: gates without octave marks;
+    // 2: gates with octave marks.  The same in every lane.
+    auto gate_begin = [&](BlockGate& bg, int mbp, int kp) {
+        int mode = 1;
         if (LEVEL) {
-            const unsigned high = (unsigned)__builtin_amdgcn_readfirstlane((int)s_high[mb][k][1]);
+            const unsigned high = (unsigned)__builtin_amdgcn_readfirstlane((int)s_high[mbp][kp]);
 #pragma unroll
             for (int b = 0; b < kMmNB; b++) {
-                if (high != 0u && any_qhigh[b]) {
-                    // both octaves above max_level: bit acc_row(i, h) of the block's mask, for the queries that are high
-                    const unsigned mine = qhigh[b] ? high >> (4 * h) : 0u;
-#pragma unroll
-                    for (int i = 0; i < 16; i++)
-                        acc[b][i] |= (int)(((mine >> acc_row(i, 0)) & 1u) << 15);
-                }
+                bg.mine[b] = qhigh[b] ? high >> (4 * h) : 0u;
+                if (high != 0u && any_qhigh[b]) mode = 2;
             }
         }
         if (AREA) {
-            const float4* px = reinterpret_cast<const float4*>(&s_meta[mb][0][k * kMmSub + 4 * h]);
-            const float4* py = reinterpret_cast<const float4*>(&s_meta[mb][1][k * kMmSub + 4 * h]);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float4 tx4 = px[2 * j], ty4 = py[2 * j];
-                const float tx[4] = {tx4.x, tx4.y, tx4.z, tx4.w}, ty[4] = {ty4.x, ty4.y, ty4.z, ty4.w};
-#pragma unroll
-                for (int b = 0; b < kMmNB; b++)
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const float dx = qx[b] - tx[c], dy = qy[b] - ty[c];
-                        if (!(fabsf(dx) < a.area && fabsf(dy) < a.area)) acc[b][4 * j + c] |= (int)kMmFail;
-                    }
+            // fl(a - b) is monotone in a and in b: if the nearest corners are a window apart, so is every pair
+            const v4f box = *reinterpret_cast<const v4f*>(&s_box[mbp][kp][0]);
+            const bool apart = box.x - qbox[1] >= a.area || qbox[0] - box.y >= a.area ||
+                               box.z - qbox[3] >= a.area || qbox[2] - box.w >= a.area;
+            if (__ballot(apart) != 0ull) return 0;
+            bg.px = (LdsRows)&s_meta[mbp][0][kp * kMmSub + 4 * h];
+            bg.py = (LdsRows)&s_meta[mbp][1][kp * kMmSub + 4 * h];
+            bg.x4 = bg.px[0]; bg.y4 = bg.py[0];
+        }
+        return mode;
+    };
+    auto gate_part = [&](v16f (&acc)[kMmNB], BlockGate& bg, int n, auto level_on) {
+        constexpr bool kLevelOn = LEVEL && decltype(level_on)::value;
+        if (!AREA && !kLevelOn) return;
+        float tx[4] = {0.f, 0.f, 0.f, 0.f}, ty[4] = {0.f, 0.f, 0.f, 0.f};
+        if (AREA) {
+            tx[0] = bg.x4.x; tx[1] = bg.x4.y; tx[2] = bg.x4.z; tx[3] = bg.x4.w;
+            ty[0] = bg.y4.x; ty[1] = bg.y4.y; ty[2] = bg.y4.z; ty[3] = bg.y4.w;
+            if (n < 3) {
+                // the next part's rows, a slice ahead (and no earlier: the addresses are made opaque here, or the
+                // compiler reads all four parts' rows up front and runs out of registers)
+                LdsRows nx = bg.px + 2 * (n + 1);
+                LdsRows ny = bg.py + 2 * (n + 1);
+                asm volatile("" : "+v"(nx), "+v"(ny));
+                bg.x4 = *nx; bg.y4 = *ny;
             }
         }
+#pragma unroll
+        for (int b = 0; b < kMmNB; b++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int i = 4 * n + c;
+                unsigned sign = 0u;
+                if (AREA) {
+                    const float dx = qx[b] - tx[c], dy = qy[b] - ty[c];
+                    sign = (unsigned)(area_bits_m1 - (int)__float_as_uint(fmaxf(fabsf(dx), fabsf(dy))));
+                }
+                if (kLevelOn) {
+                    const unsigned lv = bg.mine[b] << (31 - acc_row(i, 0));
+                    sign = AREA ? (sign | lv) : lv;
+                }
+                const float f = acc[b][i];
+                acc[b][i] = __uint_as_float((sign & kMmFail) | __float_as_uint(f));
+            }
     };
 
-    // ---- one block: 8 x kMmNB products, with a slice of other work issued behind each of them.  The slices
-    //      must not depend on this block's products; fenced so that the compiler keeps them where they are:
-    //      a wave issues in order, and about four vector instructions fit under one product ----
-    auto products = [&](v16i (&acc)[kMmNB], const v4i (&af)[kMmSteps], auto&& slice) {
+    // ---- one block: kMmSteps x kMmNB products, with a slice of other work issued behind each of them.  The
+    //      slices must not depend on this block's products; fenced so that the compiler keeps them where they are:
+    //      a wave issues in order, and about five vector instructions fit under one product ----
+    auto products = [&](v16f (&acc)[kMmNB], const v4i (&af)[kMmSteps], auto&& slice) {
 #pragma unroll
         for (int s = 0; s < kMmSteps; s++)
 #pragma unroll
             for (int b = 0; b < kMmNB; b++) {
-                acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], bq[b][s], s == 0 ? c_init : acc[b], 0, 0, 0);
+                acc[b] = product(af[s], bq[b][s], s == 0 ? c_init : acc[b], scale_a, scale_b);
                 slice(s * kMmNB + b);
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
     constexpr int kSlots = kMmSteps * kMmNB;          // slices per block
-    static_assert(kMmNB == 2, "the slices are laid out for two query blocks per wave");
+    static_assert(kMmNB == 2 && kMmSteps == 4 && kMmBT % 2 == 0, "the slices are laid out for 8 products per block and an even number of blocks per tile");
 
-    // Tile T lies in operand buffer T % 3 and metadata buffer T % 4, and is expanded two tiles ahead: while the
-    // products of tile T are issued, its two blocks' worth of slices also read the operands of the next block
-    // (block 1 of tile T, then block 0 of tile T + 1, both staged at least one barrier ago), finish the arg-min of
-    // the block before, and expand one row each of tile T + 2 (loaded from memory a tile ago) into the third
-    // buffer.  One barrier per tile, at its end, and nothing behind it waits for LDS: the next block's operands are
-    // in registers already.  What a block's gates need of its tile's metadata is read up to one tile later, hence
+    // Tile T lies in operand buffer T % 3 and metadata buffer T % 4, and is expanded two tiles ahead.  While the
+    // products of block k of tile T are issued, the slices behind them read the operands of the next block (of
+    // tile T + 1 for the last one; staged at least one barrier ago), finish the arg-min of the block before, and
+    // expand this thread's row of block k of tile T + 2 (loaded from memory a tile ago) into the third buffer.  One
+    // barrier per tile, at its end, and nothing behind it waits for LDS: the next block's operands are in
+    // registers already.  What a block's gates need of its tile's metadata is read up to one tile later, hence
     // four metadata buffers.
     const int n_tiles = (t_end - t_begin + kMmTile - 1) / kMmTile;
-    Staged g;
-    load_tile(t_begin, g);
-    stage_tile(0, g);
-    stage_meta(0, g);
-    load_tile(t_begin + kMmTile, g);            // tiles past the end are zeros
-    stage_tile(1, g);
-    stage_meta(1, g);
-    load_tile(t_begin + 2 * kMmTile, g);
+    stage_tile(0, g0);
+    stage_meta(0, g0);
+    stage_tile(1, g1);
+    stage_meta(1, g1);
     lds_barrier();
 
     v4i af0[kMmSteps], af1[kMmSteps];
 #pragma unroll
     for (int s = 0; s < kMmSteps; s++) af0[s] = operand(0, 0, s);
-    v16i acc0[kMmNB], acc1[kMmNB];
+    v16f acc0[kMmNB], acc1[kMmNB];
 #pragma unroll
     for (int b = 0; b < kMmNB; b++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc1[b][i] = 0xffff;     // "the block before the first": every pair failed
+        for (int i = 0; i < 16; i++) acc1[b][i] = 65535.f;     // "the block before the first": every pair failed
+
+    // products of one block into `acc`; behind them the gates and the arg-min of the block before (`prev`, block kp
+    // of the tile with metadata buffer mbp, first train row blockno_prev) and whatever `extra` adds
+    auto run_block = [&](v16f (&acc)[kMmNB], v16f (&prev)[kMmNB], const v4i (&af)[kMmSteps], int mbp, int kp, int blockno_prev, auto&& extra) {
+        BlockGate bg;
+        const int mode = kMeta ? gate_begin(bg, mbp, kp) : 1;
+        auto slices = [&](auto level_on) {
+            products(acc, af, [&](int n) {
+                if (kMeta && n < 4) gate_part(prev, bg, n, level_on);
+                argmin_part(prev, 2 * n, blockno_prev);
+                argmin_part(prev, 2 * n + 1, blockno_prev);
+                extra(n);
+            });
+        };
+        if (AREA && mode == 0) products(acc, af, [&](int n) { extra(n); });
+        else if (LEVEL && mode == 2) slices(std::true_type());
+        else slices(std::false_type());
+    };
+    // the same without products: the gates and the arg-min of a block that no other block follows
+    auto finish_block = [&](v16f (&prev)[kMmNB], int mbp, int kp, int blockno_prev) {
+        BlockGate bg;
+        const int mode = kMeta ? gate_begin(bg, mbp, kp) : 1;
+        if (AREA && mode == 0) return;
+#pragma unroll
+        for (int n = 0; n < kSlots; n++) {
+            if (kMeta && n < 4) { if (LEVEL && mode == 2) gate_part(prev, bg, n, std::true_type()); else gate_part(prev, bg, n, std::false_type()); }
+            argmin_part(prev, 2 * n, blockno_prev);
+            argmin_part(prev, 2 * n + 1, blockno_prev);
+        }
+    };
 
     SA_STAMP(1);
     int cur = 0, nxt = 1, nx2 = 2;            // operand buffers of tiles T, T + 1, T + 2
@@ -363,35 +514,28 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
     int blockno = 0;
     int rows_left = t_end - t_begin;
     for (int T = 0; T + 1 < n_tiles; T++) {
-        if (kMeta) apply_gates(acc1, mb_prev, 1, kMmSub);
         stage_meta(mb_nx2, g);
-        unsigned o[4];
-        // output dword n - 8 of this thread's row of a block of tile T + 2 (the empty statement keeps the two
-        // instructions in their slice: the compiler would otherwise gather them in front of the LDS write)
-        auto expand_part = [&](unsigned gw, int n, uint4* w0, uint4* w1) {
-            if (n < 8) return;
-            o[n & 3] = (gw >> (n - 8)) & 0x01010101u;
-            asm volatile("" : "+v"(o[n & 3]));
-            if ((n & 3) == 3) *(n < 12 ? w0 : w1) = make_uint4(o[0], o[1], o[2], o[3]);
-        };
-        const unsigned gw0 = g.valid[0] ? g.w[0] : 0u, gw1 = g.valid[1] ? g.w[1] : 0u;
-        {
-            uint4* const w0 = stage_slot(nx2, 0, 0); uint4* const w1 = stage_slot(nx2, 0, 1);
-            products(acc0, af0, [&](int n) {
-                if (n < kMmSteps) af1[n] = operand(cur, 1, n);
-                argmin_part(acc1, n, blockno - kMmSub);
-                expand_part(gw0, n, w0, w1);
-                if (n == 15) load_row(t_begin + (T + 3) * kMmTile, 0, g);
-            });
-        }
-        if (kMeta) apply_gates(acc0, mb, 0, kMmSub);
-        {
-            uint4* const w0 = stage_slot(nx2, 1, 0); uint4* const w1 = stage_slot(nx2, 1, 1);
-            products(acc1, af1, [&](int n) {
-                if (n < kMmSteps) af0[n] = operand(nxt, 0, n);
-                argmin_part(acc0, n, blockno);
-                expand_part(gw1, n, w0, w1);
-                if (n == 15) load_row(t_begin + (T + 3) * kMmTile, 1, g);
+#pragma unroll
+        for (int k = 0; k < kMmBT; k++) {
+            v16f (&acc)[kMmNB] = (k & 1) ? acc1 : acc0;
+            v16f (&prev)[kMmNB] = (k & 1) ? acc0 : acc1;
+            const v4i (&af)[kMmSteps] = (k & 1) ? af1 : af0;
+            v4i (&af_next)[kMmSteps] = (k & 1) ? af0 : af1;
+            uint4* const wslot = stage_slot(nx2, k);
+            unsigned o[4];
+            run_block(acc, prev, af, k == 0 ? mb_prev : mb, k == 0 ? kMmBT - 1 : k - 1, blockno + (k - 1) * kMmSub, [&](int n) {
+                if (n < kMmSteps) af_next[n] = k + 1 < kMmBT ? operand(cur, k + 1, n) : operand(nxt, 0, n);
+                if (n >= 4) {
+                    // output dword n - 4 of this thread's row of block k of tile T + 2 (the empty statement keeps the
+                    // two instructions in their slice: the compiler would otherwise gather them in front of the write)
+                    o[n - 4] = (g.w[k] >> (n - 4)) & 0x11111111u;
+                    asm volatile("" : "+v"(o[n - 4]));
+                    if (n == 7) {
+                        *wslot = make_uint4(o[0], o[1], o[2], o[3]);
+                        load_row(t_begin + (T + 3) * kMmTile, k, g);
+                        if (k == kMmBT - 1) load_meta(t_begin + (T + 3) * kMmTile, g);
+                    }
+                }
             });
         }
         lds_barrier();
@@ -403,25 +547,41 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
         mb_nx2 = (mb_nx2 + 1) & 3;
     }
     SA_STAMP(2);
-    // the last tile: nothing to stage; its blocks may be cut short by the end of the set
-    {
-        if (kMeta) apply_gates(acc1, mb_prev, 1, kMmSub);
-        products(acc0, af0, [&](int n) {
-            if (n < kMmSteps) af1[n] = operand(cur, 1, n);
-            argmin_part(acc1, n, blockno - kMmSub);
-        });
-        apply_gates(acc0, mb, 0, rows_left);
-        products(acc1, af1, [&](int n) { argmin_part(acc0, n, blockno); });
-        apply_gates(acc1, mb, 1, rows_left - kMmSub);
+    // the last tile: nothing to stage; the end of the set may cut its blocks short or leave them empty
 #pragma unroll
-        for (int n = 0; n < kSlots; n++) argmin_part(acc1, n, blockno + kMmSub);
+    for (int k = 0; k < kMmBT; k++) {
+        v16f (&acc)[kMmNB] = (k & 1) ? acc1 : acc0;
+        v16f (&prev)[kMmNB] = (k & 1) ? acc0 : acc1;
+        const v4i (&af)[kMmSteps] = (k & 1) ? af1 : af0;
+        v4i (&af_next)[kMmSteps] = (k & 1) ? af0 : af1;
+        if (k > 0) gate_tail(prev, rows_left - (k - 1) * kMmSub);
+        const int mbp = k == 0 ? mb_prev : mb, kp = k == 0 ? kMmBT - 1 : k - 1, bprev = blockno + (k - 1) * kMmSub;
+        if (k == 0 || rows_left > k * kMmSub) {
+            run_block(acc, prev, af, mbp, kp, bprev, [&](int n) {
+                if (n < kMmSteps && k + 1 < kMmBT) af_next[n] = operand(cur, k + 1, n);
+            });
+        } else {
+            // an empty block: only the block before it is left to finish; its own accumulators all fail
+            finish_block(prev, mbp, kp, bprev);
+#pragma unroll
+            for (int b = 0; b < kMmNB; b++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[b][i] = 65535.f;
+        }
     }
+    {
+        v16f (&lastacc)[kMmNB] = ((kMmBT - 1) & 1) ? acc1 : acc0;
+        gate_tail(lastacc, rows_left - (kMmBT - 1) * kMmSub);
+        finish_block(lastacc, mb, kMmBT - 1, blockno + (kMmBT - 1) * kMmSub);
+    }
+
 #pragma unroll
     for (int b = 0; b < kMmNB; b++) {
-        const unsigned ob = (unsigned)__shfl_xor((int)best[b], 32, 64);
-        const unsigned m = min(best[b], ob);
-        // m = (H - popcount(query) + 256) << 20 | train row relative to t_begin; pairs that failed a gate and rows
-        // beyond the set carry distances above 256
+        // this lane half's best as a key (H - popcount(query) + 256) << 20 | train row relative to t_begin
+        const unsigned mine = SECOND ? best[b] : bits_key(best[b], (int)best_blk[b]);
+        const unsigned ob = (unsigned)__shfl_xor((int)mine, 32, 64);
+        const unsigned m = min(mine, ob);
+        // pairs that failed a gate and rows beyond the set carry distances above 256
         auto final_key = [&](unsigned v) -> unsigned {
             const unsigned d = (v >> kMmIdxBits) + (unsigned)pq[b] - 256u;
             const unsigned t = (unsigned)t_begin + (v & ((1u << kMmIdxBits) - 1u));
@@ -429,7 +589,7 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
         };
         if (SECOND) {
             const unsigned os = (unsigned)__shfl_xor((int)second[b], 32, 64);
-            const unsigned m2 = min(max(best[b], ob), min(second[b], os));
+            const unsigned m2 = min(max(mine, ob), min(second[b], os));
             if (h == 0 && qidx[b] < nq)
                 a.part[(size_t)split * a.part_pitch + qbase + qidx[b]] = make_uint2(final_key(m), final_key(m2));
             continue;

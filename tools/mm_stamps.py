@@ -50,8 +50,8 @@ print("real-time clock at wave start (10 ns ticks): spread %d" % (rt.max() - rt.
 order = np.argsort(rt)
 print("start real-time percentiles (us after the first): p50 %.2f p90 %.2f max %.2f" % tuple(
     (np.percentile(rt, q) - rt.min()) / 100.0 for q in (50, 90, 100)))
-tiles = np.ceil(cnt.cpu().numpy().astype(np.float64) / 64).mean()
-print("tiles per wave ~%.1f -> cycles per tile in the loop: median %.0f (products alone: 1024)" % (tiles, np.median(loop) / max(tiles - 1, 1)))
+tiles = np.ceil(cnt.cpu().numpy().astype(np.float64) / 128).mean()
+print("tiles per wave ~%.1f -> cycles per tile in the loop: median %.0f (products alone: 1024 for 128 rows)" % (tiles, np.median(loop) / max(tiles - 1, 1)))
 # co-residency: how many waves share (se, sh, cu, simd)
 key = ((se * 2 + sh) * 16 + cu) * 4 + simd
 uniq, c = np.unique(key, return_counts=True)
