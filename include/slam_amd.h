@@ -200,7 +200,7 @@ int slam_amd_matcher_set_options(slam_amd_matcher* m, float ratio, int histo_len
 /* Test hook.  With the window gate on (area != -1) large problems are matched after
  * reordering both sets by grid cell, visiting only train tiles near each group of
  * queries; the result is identical to the full sweep.  mode 0 chooses by size
- * (queries x train rows >= 2^25), 1 forces the full sweep, 2 forces the cell-sorted path. */
+ * (queries x train rows >= 2^30), 1 forces the full sweep, 2 forces the cell-sorted path. */
 int slam_amd_matcher_debug_set_window_mode(slam_amd_matcher* m, int mode);
 
 /* Test hook.  The full sweep (every query against every train row) forms its distances on the

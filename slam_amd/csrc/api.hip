@@ -66,6 +66,12 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+static bool stream_capturing(hipStream_t st) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &status) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return status == hipStreamCaptureStatusActive;
+}
+
 static int use_device(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -107,8 +113,9 @@ struct slam_amd_extractor {
     DevBuf tiledesc;                   // level and tile coordinates of every FAST tile of a frame
     DevBuf lanegeom;                   // level geometry as a table in device memory: one level per lane of the describe kernel
     int select_keycap = 4096;          // kept survivors of a level ranked from LDS (debug knob)
-    bool hist_clean = false;           // the score histograms are all zero: the describe kernel zeroes them after the selection
-                                       // has read them; a call that fails before that leaves this false
+    bool hist_clean = false;           // the score histograms are all zero once the work enqueued so far has run: zeroed at creation,
+                                       // and by the describe kernel after the selection has read them; a call that fails
+                                       // in between enqueues the fill itself before it returns
     // host-call staging
     DevBuf h_img, h_kp, h_desc, h_count;
     int h_img_pitch = 0;
@@ -508,11 +515,13 @@ extern "C" int slam_amd_extractor_create(const slam_amd_orb_params* params, int 
     }
     // packed positions start out as zeros: a slot that was never written decodes to (0, 0, level 0),
     // which the describe kernel rejects, instead of an arbitrary address
-    if (hipMemset(ex->kpxy.p, 0, ex->kpxy.cap) != hipSuccess || hipMemset(ex->sel.p, 0, ex->sel.cap) != hipSuccess) {
+    if (hipMemset(ex->kpxy.p, 0, ex->kpxy.cap) != hipSuccess || hipMemset(ex->sel.p, 0, ex->sel.cap) != hipSuccess ||
+        hipMemset(ex->hist.p, 0, ex->hist.cap) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         (void)hipGetLastError();
         set_error("hipMemset of the selection buffers failed");
         return fail(SLAM_AMD_ERR_HIP);
     }
+    ex->hist_clean = true;
     hipError_t e = hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(hip_fail(e, "hipStreamCreateWithFlags", __FILE__, __LINE__));
     *out = ex;
@@ -563,11 +572,24 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
                         (batch == 1 || frame_pitch % 4 == 0);
     ex->last_img0 = d_images; ex->last_frame_pitch = frame_pitch; ex->last_row_stride = row_stride;
 
+    // The histograms must be all zero when this call's FAST kernel runs.  Every completed call leaves them so (the
+    // describe kernel zeroes them), so does creation; only a call that failed half way and could not even enqueue the
+    // fill leaves the flag down.  Under stream capture nothing runs now: the flag describes the buffer, not the
+    // recording, and stays as it is (a recording made while it is down carries its own fill).
+    const bool capturing = stream_capturing(st);
     if (!ex->hist_clean) {
         ProfScope ps(kStageMemset, st);
         SA_HIP(hipMemsetAsync(ex->hist.p, 0, ex->hist.cap, st));
     }
-    ex->hist_clean = false;     // until this call's describe kernel is in the stream
+    struct Restore {        // an eager call that returns early puts the histograms back to zero behind whatever it enqueued
+        slam_amd_extractor* ex; hipStream_t st; bool armed;
+        ~Restore() {
+            if (!armed) return;
+            ex->hist_clean = hipMemsetAsync(ex->hist.p, 0, ex->hist.cap, st) == hipSuccess;
+            if (!ex->hist_clean) (void)hipGetLastError();
+        }
+    } restore = {ex, st, !capturing};
+    if (!capturing) ex->hist_clean = false;     // until this call's describe kernel is in the stream
     int rc;
     prof_mark(kStageResize, true, st);
     for (const slam_amd_extractor::PyrGroupPlan& pg : ex->pyr_groups) {
@@ -600,7 +622,8 @@ extern "C" int slam_amd_extract_batch_async(slam_amd_extractor* ex, const uint8_
     da.kpxy = ex->kpxy.as<uint32_t>(); da.lanegeom = ex->lanegeom.as<int32_t>(); da.desc = d_desc; da.capacity = capacity; da.batch = batch; da.g = g;
     da.hist_reset = ex->hist.as<unsigned>();
     { ProfScope ps(kStageDescribe, st); if ((rc = launch_describe(da, batch, st))) return rc; }
-    ex->hist_clean = true;
+    restore.armed = false;
+    if (!capturing) ex->hist_clean = true;
     return SLAM_AMD_OK;
 }
 
@@ -743,8 +766,9 @@ struct slam_amd_matcher {
     DevBuf part;                       // per-split (best, second) keys when the ratio test is on
     DevBuf sorted;                     // both sets in grid-cell order for windowed matching
     bool baked = false;                // an _async call ran under stream capture: scratch pointers live in a graph
-    bool best_clean = false;           // every key of `best` is "no match": the finalize kernel puts back what it reads, a call that
-                                       // fails half way leaves this false and the next one fills the whole buffer
+    bool best_clean = false;           // every key of `best` is "no match" once the work enqueued so far has run: filled when it is
+                                       // allocated, the finalize kernel puts back what it reads, and a call that fails
+                                       // in between enqueues the fill itself before it returns
     unsigned char* static_scratch = nullptr;  // this device's copy of the file-scope scratch array (no-alloc entry point)
     int window_mode = 0;               // 0: choose by size, 1: always the full sweep, 2: always cell-sorted
     int sweep_kernel = 0;              // full sweep: 0 = matrix-core kernel (gates and ratio option included), 1 = VALU popcount kernel
@@ -804,19 +828,18 @@ extern "C" int slam_amd_matcher_destroy(slam_amd_matcher* m) {
 // that every hipMemsetAsync covers whole 16-byte multiples.
 static size_t fill_bytes(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
-static bool stream_capturing(hipStream_t st) {
-    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &status) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return status == hipStreamCaptureStatusActive;
-}
-
 static int grow_scratch(slam_amd_matcher* m, DevBuf& b, size_t bytes, bool capturing) {
     if (bytes <= b.cap) return SLAM_AMD_OK;
     if (capturing || m->baked)
         SA_FAIL(SLAM_AMD_ERR_CAPACITY, "matcher scratch too small and a captured graph holds (or is recording) its "
                                        "address: call slam_amd_matcher_reserve with the largest sizes before capturing");
-    if (&b == &m->best) m->best_clean = false;      // fresh memory
-    return b.reserve(bytes);
+    const int rc = b.reserve(bytes);
+    if (rc == SLAM_AMD_OK && &b == &m->best) {
+        // fresh memory starts out as "no match" physically, not by a fill that a later call (perhaps only recorded) enqueues
+        m->best_clean = hipMemset(b.p, 0xff, b.cap) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+        if (!m->best_clean) { (void)hipGetLastError(); SA_FAIL(SLAM_AMD_ERR_HIP, "fill of the matcher scratch failed"); }
+    }
+    return rc;
 }
 
 // Byte layout of the cell-sorted copies of both sets (set 0 = queries, 1 = train): per row
@@ -906,11 +929,12 @@ static int match_common(slam_amd_matcher* m, int batch,
     const bool second = m->ratio > 0.f;
     if (m->histo_length > 0 && nq > 0 && n2 > 0 && (!k1 || !k2))
         SA_FAIL(SLAM_AMD_ERR_ARG, "the rotation-consistency option needs the keypoints of both sets");
-    // With the window gate on and sets large enough to repay the reordering, both sets
-    // are sorted by grid cell and only nearby tiles are compared; same result.
+    // With the window gate on and sets large enough to repay the reordering (from about 10^9 pairs: below that
+    // the full sweep on the matrix cores, which skips blocks of rows a window away, is faster), both sets are
+    // sorted by grid cell and only nearby tiles are compared; same result.
     bool windowed = area > 0.f && area <= 3.0e38f && nq > 0 && n2 > 0;
     if (m->window_mode == 1 || no_alloc || chain) windowed = false;   // the full sweep needs no reordered copies
-    else if (m->window_mode == 0) windowed = windowed && (long long)nq * n2 >= (1LL << 25);
+    else if (m->window_mode == 0) windowed = windowed && (long long)nq * n2 >= (1LL << 30);
     // full sweep: distances on the matrix cores (gates and second-best keys included)
     const bool use_mfma = m->sweep_kernel == 0;
     MatchPlan plan = use_mfma ? plan_match_mfma(batch, nq, n2, m->n_cu, second) : plan_match(batch, nq, n2, m->n_cu, second);
@@ -937,12 +961,22 @@ static int match_common(slam_amd_matcher* m, int batch,
     // The matcher's own single plane is kept in that state by the finalize kernel, which puts back
     // every key it reads; it is filled whole after it was allocated or a call did not get that far.
     const bool self_clean = !no_alloc && !second;
+    struct Restore {        // an eager call that returns early puts the keys back to "no match" behind whatever it enqueued,
+                            // so that a graph recorded without a fill still finds them clean when it is replayed
+        slam_amd_matcher* m; hipStream_t st; bool armed;
+        ~Restore() {
+            if (!armed) return;
+            m->best_clean = hipMemsetAsync(m->best.p, 0xff, m->best.cap, st) == hipSuccess;
+            if (!m->best_clean) (void)hipGetLastError();
+        }
+    } restore = {m, st, false};
     if (self_clean) {
         if (!m->best_clean) {
             ProfScope ps(kStageMemset, st);
             SA_HIP(hipMemsetAsync(m->best.p, 0xff, m->best.cap, st));
         }
-        m->best_clean = false;      // until this call's finalize kernel is in the stream
+        // Under capture nothing runs now: the flag describes the buffer, not the recording, and stays as it is.
+        if (!capturing) { m->best_clean = false; restore.armed = true; }    // until this call's finalize kernel is in the stream
     } else {
         const size_t bytes = second ? fill_bytes(rows * plan.splits * sizeof(uint2)) : fill_bytes(rows * sizeof(unsigned));
         ProfScope ps(kStageMemset, st);
@@ -1005,7 +1039,7 @@ static int match_common(slam_amd_matcher* m, int batch,
     if (capturing) m->baked = true;
     ProfScope ps(kStageFinalize, st);
     rc = launch_finalize(f, batch, st);
-    if (rc == SLAM_AMD_OK && self_clean) m->best_clean = true;
+    if (rc == SLAM_AMD_OK && restore.armed) { restore.armed = false; m->best_clean = true; }
     return rc;
 }
 

@@ -57,7 +57,6 @@ constexpr int kMmSteps = 4;                   // products per block: 64 descript
 constexpr int kMmSubU4 = kMmSteps * 64;       // uint4 slots of one expanded block of 32 rows: [step][half][row]
 constexpr unsigned kMmNoMatch = 0xffffffffu;
 constexpr int kMmIdxBits = 20;
-constexpr int kMmBlockBits = 15;              // kMmIdxBits minus the 5 row bits an accumulator carries
 constexpr int kMmBias = 32768 + 32 * 256;     // accumulators in [2^15, 2^16): one binade, H - popcount(b) >= -256
 constexpr unsigned kMmBinade = 0x47000000u;   // bit pattern of 32768.f; an accumulator's is kMmBinade + (32 Hb + row) << 8
 constexpr unsigned kMmRowBits = 31u << 8;

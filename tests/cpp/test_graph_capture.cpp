@@ -8,6 +8,9 @@
 //    (SLAM_AMD_ERR_CAPACITY when its scratch is too small), and after a call has been
 //    captured the scratch never moves (a larger call is refused instead of freeing a
 //    pointer an instantiated graph still holds).
+// 3. The scratch that the kernels leave clean for the next call (score histograms, running match keys): a
+//    recording made by the very first call of fresh contexts, replayed after eager calls and after another
+//    recording; and an eager call that fails half way between recording and replay.
 // Needs a GPU.  Exit code 0 = all checks passed.  Every HIP failure ends the program at
 // once: nothing is retried on a device that reported an error.
 #include <hip/hip_runtime_api.h>
@@ -193,6 +196,61 @@ int main() {
         HIP(hipGraphExecDestroy(e));
         HIP(hipGraphDestroy(g));
         OK(slam_amd_matcher_destroy(m2));
+    }
+
+    // ---- self-cleaning scratch: first call recorded, eager calls and a failing call before the replay ----
+    {
+        slam_amd_extractor* ex3 = nullptr;
+        slam_amd_matcher* m3 = nullptr;
+        OK(slam_amd_extractor_create(&p, W, H, B, CAP, 0, &ex3));
+        OK(slam_amd_matcher_create(0, &m3));
+        OK(slam_amd_matcher_reserve(m3, B, CAP, 0));      // no room for the cell-sorted copies: the windowed call below must fail
+        auto step3 = [&](int batch) {
+            OK(slam_amd_extract_batch_async(ex3, b.img, batch, (size_t)W * H, W,
+                                            reinterpret_cast<slam_amd_keypoint*>(b.kp + (size_t)CAP * KP), b.desc + (size_t)CAP * 32,
+                                            b.cnt + 1, CAP, s));
+            OK(slam_amd_frame_match_batch_async(m3, batch, b.desc, reinterpret_cast<slam_amd_keypoint*>(b.kp), CAP, b.cnt,
+                                                b.desc + (size_t)CAP * 32, reinterpret_cast<slam_amd_keypoint*>(b.kp + (size_t)CAP * KP),
+                                                CAP, b.cnt + 1, 300.f, -1.f, -1,
+                                                reinterpret_cast<slam_amd_dmatch*>(b.out), b.nout, s));
+        };
+        hipGraph_t g1 = nullptr, g2 = nullptr;
+        hipGraphExec_t e1 = nullptr, e2 = nullptr;
+        HIP(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        step3(B);                                         // the contexts' first call is a recording: nothing runs
+        HIP(hipStreamEndCapture(s, &g1));
+        HIP(hipGraphInstantiate(&e1, g1, nullptr, nullptr, 0));
+        clear_outputs(b, s); step3(B);                    // an eager call before the first replay
+        EXPECT(snapshot(b, B, s) == ref_batch, "eager call after a recorded first call differs from the reference");
+        HIP(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+        step3(B);
+        HIP(hipStreamEndCapture(s, &g2));
+        HIP(hipGraphInstantiate(&e2, g2, nullptr, nullptr, 0));
+        clear_outputs(b, s);
+        HIP(hipGraphLaunch(e2, s));                       // the second recording runs first
+        EXPECT(snapshot(b, B, s) == ref_batch, "second recording differs from the reference");
+        clear_outputs(b, s);
+        HIP(hipGraphLaunch(e1, s));
+        EXPECT(snapshot(b, B, s) == ref_batch, "first recording differs from the reference");
+        // an eager windowed call that fails after it has started (its reordered copies cannot be allocated: recordings
+        // hold the scratch), then the replays again
+        OK(slam_amd_matcher_debug_set_window_mode(m3, 2));
+        const int rc_fail = slam_amd_frame_match_batch_async(m3, B, b.desc, reinterpret_cast<slam_amd_keypoint*>(b.kp), CAP, b.cnt,
+                                                             b.desc + (size_t)CAP * 32, reinterpret_cast<slam_amd_keypoint*>(b.kp + (size_t)CAP * KP),
+                                                             CAP, b.cnt + 1, 300.f, 40.f, -1,
+                                                             reinterpret_cast<slam_amd_dmatch*>(b.out), b.nout, s);
+        EXPECT(rc_fail == SLAM_AMD_ERR_CAPACITY, "the windowed call without room for its copies returned %d", rc_fail);
+        OK(slam_amd_matcher_debug_set_window_mode(m3, 0));
+        clear_outputs(b, s);
+        HIP(hipGraphLaunch(e1, s));
+        EXPECT(snapshot(b, B, s) == ref_batch, "replay after a failed eager call differs from the reference");
+        clear_outputs(b, s); step3(B);
+        EXPECT(snapshot(b, B, s) == ref_batch, "eager call after a failed eager call differs from the reference");
+        HIP(hipGraphExecDestroy(e1)); HIP(hipGraphExecDestroy(e2));
+        HIP(hipGraphDestroy(g1)); HIP(hipGraphDestroy(g2));
+        OK(slam_amd_extractor_destroy(ex3));
+        OK(slam_amd_matcher_destroy(m3));
+        printf("recordings made before any call ran, and replays after a failed call, reproduce the eager results\n");
     }
 
     HIP(hipGraphExecDestroy(e_batch)); HIP(hipGraphExecDestroy(e_one));
