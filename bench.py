@@ -42,9 +42,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
 CLOCK_GHZ = 2.4
 N_SIMD = 1024                  # 256 CUs x 4 SIMD-32; a wave64 VALU instruction holds one for 2 cycles
 VALU_NOMINAL_GCMP = 4914.0     # 256 CU x 128 lanes/clk x 2.4 GHz / 16 ops, for reference only
-# matrix-core ceiling of the ungated matcher: a 32 x 32 block of (train, query) pairs costs 9
-# v_mfma_i32_32x32x32_i8 of 32 cycles each on one of the 1024 SIMDs
-MFMA_I8_PEAK_GCMP = N_SIMD * 2.4e9 * 1024 / (9 * 32) / 1e9
+# matrix-core ceiling of the matcher: a 32 x 32 block of (train, query) pairs costs 4
+# v_mfma_scale_f32_32x32x64_f8f6f4 on 4-bit operands, 32 cycles each on one of the 1024 SIMDs
+MFMA_F4_PEAK_GCMP = N_SIMD * 2.4e9 * 1024 / (4 * 32) / 1e9
 
 
 def valu_peak_gcmp():
@@ -239,9 +239,8 @@ def run_frames(args):
     ws, hs, quotas, scales = ex.levels()
 
     # ---- inputs: a drifting sequence of one synthetic scene, resident in HBM ----
-    n_distinct = min(B, 8)
-    seq = synth.frame_sequence(W, H, n_distinct, seed=1 + rank)
-    frames = np.stack([seq[i % n_distinct] for i in range(B)])
+    seq = synth.frame_sequence(W, H, B, seed=1 + rank)     # B distinct frames
+    frames = np.stack(seq)
     d_img = torch.from_numpy(frames).to(dev)
     KP, DM = 28, 16
     # Two sets of result arrays used in turn: a step extracts its batch into one set and matches frame b
@@ -257,8 +256,9 @@ def run_frames(args):
     class Step:
         """One step; successive calls alternate between the two sets, eager or as a pair of HIP graphs."""
 
-        def __init__(self, matcher, batch):
+        def __init__(self, matcher, batch, area=-1.0, max_level=-1):
             self.matcher, self.batch, self.graphs = matcher, batch, None
+            self.area, self.max_level = area, max_level
 
         def launch(self, parity):
             st = cur["stream"]
@@ -269,7 +269,7 @@ def run_frames(args):
             self.matcher.frame_match_chain_async(self.batch, p["desc"].data_ptr() + last * CAP * 32,
                                                  p["kp"].data_ptr() + last * CAP * KP, p["cnt"].data_ptr() + 4 * last,
                                                  c["desc"].data_ptr(), c["kp"].data_ptr(), CAP, c["cnt"].data_ptr(),
-                                                 d_out, d_nout, max_dist=300.0, area=-1.0, max_level=-1, stream=st)
+                                                 d_out, d_nout, max_dist=300.0, area=self.area, max_level=self.max_level, stream=st)
 
         def __call__(self):
             self.launch(cur["parity"])
@@ -282,6 +282,8 @@ def run_frames(args):
     step = Step(m, B)
     one_frame = Step(m, 1)
     step_ratio = Step(m_ratio, B)
+    step_octave = Step(m, B, -1.0, 4)          # frameMatch(..., 300, -1, 4) as Mapper::initialize calls it
+    step_window = Step(m, B, 50.0, 4)          # ... and with the 50-pixel window of the tracker's calls
 
     def capture(fn):
         """fn's launches as HIP graphs, one per set (None if capture is not possible)."""
@@ -390,7 +392,7 @@ def run_frames(args):
             pmc = pmc_counters(key, B, W, H)
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                        "traffic": pmc.get("traffic"),
+                        "traffic": pmc.get("traffic"), "traffic_source": pmc.get("source"),
                         "avg_launch_us": round(avg_s * 1e6, 2),
                         "algorithmic_bytes_per_launch": int(alg_bytes[key])}
             if pmc.get("valu_wave_insts"):
@@ -436,6 +438,17 @@ def run_frames(args):
         extra["ratio_test_0.8"] = {"frames_per_s": round(world * B * args.steps / tr, 2),
                                    "ms_per_step": round(tr / args.steps * 1e3, 4),
                                    "matches_per_frame": round(float(d_nout.cpu().numpy().mean()), 1)}
+        # ---- the same step with the reference's gates: octave gate (mapper.cpp:34), window + octave (tracker.cpp:74) ----
+        for key, st_g in (("octave_gate_4", step_octave), ("window_50_octave_4", step_window)):
+            g_g = capture(st_g) if want_graph else None
+            timed_g = g_g.replay if g_g is not None else st_g
+            for _ in range(args.warmup):
+                timed_g()
+            tg = statistics.median(timed_repeats(ranks, timed_g, args.steps, min(3, args.repeats)))
+            extra[key] = {"frames_per_s": round(world * B * args.steps / tg, 2),
+                          "ms_per_step": round(tg / args.steps * 1e3, 4),
+                          "vs_gates_off": round(dt / tg, 4),
+                          "matches_per_frame": round(float(d_nout.cpu().numpy().mean()), 1)}
         # ---- frames arriving in pinned host memory: H2D, compute and D2H overlapped ----
         extra["host_pipelined"] = run_host_pipelined(args, torch, ranks, ex, m, frames, dev, world)
 
@@ -563,7 +576,7 @@ def pmc_counters(kernel, batch, width, height):
     k = rec.get("kernels", {}).get(kernel)
     if not k or rec.get("batch") != batch or rec.get("width") != width or rec.get("height") != height:
         return {}
-    out = {}
+    out = {"source": "profiles/pmc_counters.json (rocprofv3 --pmc passes of %s)" % rec.get("source_commit", rec.get("tag", "an earlier build"))}
     if "fetch_size_kib" in k and "write_size_kib" in k:
         out["traffic"] = int(2 * k["fetch_size_kib"] * 1024 + k["write_size_kib"] * 1024)
     if "sq_insts_valu" in k:
@@ -613,11 +626,12 @@ def run_pairs(args, torch, dist, capi, synth, m, dev, ranks, valu_peak):
                        % (n_kf, n_per, n_pairs),
            "gcmp_per_s": round(total_cmp / dt / 1e9, 1), "seconds": round(dt, 4), "n_gpus": world,
            "scaling": "strong",
-           # gates off: distances come from v_mfma_i32_32x32x32_i8, nine K-steps of 32 cycles per
-           # 32 x 32 block of pairs on each of the 1024 SIMDs
-           "bound": "mfma", "mfma_peak_gcmp_per_gpu": MFMA_I8_PEAK_GCMP,
-           "mfma_frac": round(total_cmp / dt / 1e9 / (MFMA_I8_PEAK_GCMP * world), 4),
-           "mfma_i8_tops": round(total_cmp / dt * 9 * 32 * 2 / 1e12, 1),
+           # distances come from v_mfma_scale_f32_32x32x64_f8f6f4 on 4-bit operands: four products of 32 cycles
+           # per 32 x 32 block of pairs on each of the 1024 SIMDs (the ceiling is priced at 2.4 GHz; the chip
+           # holds about 1.9 GHz under this load)
+           "bound": "mfma", "mfma_peak_gcmp_per_gpu": MFMA_F4_PEAK_GCMP,
+           "mfma_frac": round(total_cmp / dt / 1e9 / (MFMA_F4_PEAK_GCMP * world), 4),
+           "mfma_f4_tmac_per_s": round(total_cmp / dt * 256 / 1e12, 1),
            # the popcount kernel's measured ceiling (used with a gate on), for comparison
            "valu_peak_gcmp_per_gpu": valu_peak,
            "host": "C++ pair shard (slam_amd_pair_shard_*), RCCL send/recv in %d chunks" % args.pair_chunks}
@@ -628,6 +642,21 @@ def run_pairs(args, torch, dist, capi, synth, m, dev, ranks, valu_peak):
                                         "version": 2, "strides": None}
         d_out = torch.as_tensor(_Table(), device=dev)
         res["checksum"] = int(d_out.to(torch.int64).sum().item())
+        # a dozen pairs recomputed with numpy: the rate above belongs to a checked result
+        rng = np.random.default_rng(0)
+        bad = 0
+        sample = rng.integers(0, n_pairs, 12)
+        for r in sample:
+            i, j = pairs[r]
+            bi = np.unpackbits(desc[i * n_per:(i + 1) * n_per], axis=1).astype(np.float32)
+            bj = np.unpackbits(desc[j * n_per:(j + 1) * n_per], axis=1).astype(np.float32)
+            full = (bi.sum(1)[:, None] + bj.sum(1)[None, :] - 2 * (bi @ bj.T)).astype(np.int32)     # exact: small integers
+            want = (full.min(1).astype(np.uint32) << 16) | full.argmin(1).astype(np.uint32)   # argmin = lowest index
+            got = d_out[int(r)].cpu().numpy().view(np.uint32)
+            bad += int(not np.array_equal(got, want))
+        res["checked_pairs"] = {"sampled": len(sample), "differ": bad}
+        if bad:
+            raise RuntimeError("%d of %d sampled keyframe pairs differ from the numpy recomputation" % (bad, len(sample)))
     shard.close()
     return res
 

@@ -109,7 +109,7 @@ __device__ __forceinline__ constexpr int acc_row(int i, int h) { return 8 * (i >
 // (best, second) pair and the finalize kernel merges the splits.
 // AREA / LEVEL: the window and octave gates.
 template <bool PAIRS, bool SECOND, bool AREA, bool LEVEL>
-__global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
+__global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : 3) void match_mfma_kernel(MatchArgs a) {
     __shared__ uint4 s_tile[3][kMmBT * kMmSubU4];
     // per tile, four deep: the rows' positions (x, then y) and per block of 32 rows the mask of the rows with
     // octave > max_level
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
     // the host's bound repeat the last one below it; rows past the count are dropped at the end)
     const int nq_bound = PAIRS ? a.n_per : (a.ids ? a.n_ids : a.n1);
     if (nq_bound <= 0) return;
-    uint4 q0[kMmNB], q1[kMmNB];
+    unsigned qw[kMmNB][kMmSteps];      // dword 2s + h of the descriptor for product s
     int qidx[kMmNB];
     float qx[kMmNB], qy[kMmNB];
     int qoct[kMmNB];
@@ -234,8 +234,8 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
         qidx[b] = qi;
         const int qc = min(qi, nq_bound - 1);
         const size_t row = qs.base + (size_t)((!PAIRS && a.ids) ? a.ids[qc] : qc);
-        q0[b] = reinterpret_cast<const uint4*>(qs.desc + row * 32)[0];
-        q1[b] = reinterpret_cast<const uint4*>(qs.desc + row * 32)[1];
+#pragma unroll
+        for (int s = 0; s < kMmSteps; s++) qw[b][s] = reinterpret_cast<const unsigned*>(qs.desc + row * 32)[2 * s + h];
         qx[b] = qy[b] = 0.f;
         qoct[b] = 0;
         if (AREA) {
@@ -269,13 +269,11 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
             if ((__float_as_uint(qy[b]) & 0x7f800000u) == 0x7f800000u) qy[b] = __uint_as_float(0xff800000u);
         }
         any_qhigh[b] = LEVEL && __ballot(qhigh[b]) != 0ull;
-        // dword 2s + h of the descriptor for product s
-        const unsigned w[kMmSteps] = {h ? q0[b].y : q0[b].x, h ? q0[b].w : q0[b].z, h ? q1[b].y : q1[b].x, h ? q1[b].w : q1[b].z};
         int pc = 0;
 #pragma unroll
         for (int s = 0; s < kMmSteps; s++) {
-            pc += __builtin_popcount(w[s]);
-            bq[b][s] = expand_query(w[s]);
+            pc += __builtin_popcount(qw[b][s]);
+            bq[b][s] = expand_query(qw[b][s]);
         }
         pq[b] = pc + __shfl_xor(pc, 32, 64);
     }
@@ -455,7 +453,7 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
     static_assert(kMmNB == 2 && kMmSteps == 4 && kMmBT % 2 == 0, "the slices are laid out for 8 products per block and an even number of blocks per tile");
 
     // Tile T lies in operand buffer T % 3 and metadata buffer T % 4, and is expanded two tiles ahead.  While the
-    // products of block k of tile T are issued, the slices behind them read the operands of the next block (of
+    // products of block k of tile T are issued, the slices behind them refill the operand registers for the next block (of
     // tile T + 1 for the last one; staged at least one barrier ago), finish the arg-min of the block before, and
     // expand this thread's row of block k of tile T + 2 (loaded from memory a tile ago) into the third buffer.  One
     // barrier per tile, at its end, and nothing behind it waits for LDS: the next block's operands are in
@@ -468,9 +466,17 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
     stage_meta(1, g1);
     lds_barrier();
 
+    // The operands of a block.  Without gates one set of registers, refilled for the next block product by product as
+    // they fall free (slot 2s + 1 is the last to use operand s), which leaves room for a third wave per SIMD; with
+    // gates two sets in turn, the next block's read in the first slots (the gate code in the later slots wants the
+    // LDS to itself, and two waves per SIMD is all the registers allow there anyway).
     v4i af0[kMmSteps], af1[kMmSteps];
 #pragma unroll
     for (int s = 0; s < kMmSteps; s++) af0[s] = operand(0, 0, s);
+    auto refill = [&](v4i (&afn)[kMmSteps], int n, int buf, int k) {
+        if (kMeta) { if (n < kMmSteps) afn[n] = operand(buf, k, n); }
+        else if (n & 1) afn[n >> 1] = operand(buf, k, n >> 1);
+    };
     v16f acc0[kMmNB], acc1[kMmNB];
 #pragma unroll
     for (int b = 0; b < kMmNB; b++)
@@ -518,12 +524,12 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
         for (int k = 0; k < kMmBT; k++) {
             v16f (&acc)[kMmNB] = (k & 1) ? acc1 : acc0;
             v16f (&prev)[kMmNB] = (k & 1) ? acc0 : acc1;
-            const v4i (&af)[kMmSteps] = (k & 1) ? af1 : af0;
-            v4i (&af_next)[kMmSteps] = (k & 1) ? af0 : af1;
+            const v4i (&af)[kMmSteps] = (kMeta && (k & 1)) ? af1 : af0;
+            v4i (&afn)[kMmSteps] = (kMeta && !(k & 1)) ? af1 : af0;
             uint4* const wslot = stage_slot(nx2, k);
             unsigned o[4];
             run_block(acc, prev, af, k == 0 ? mb_prev : mb, k == 0 ? kMmBT - 1 : k - 1, blockno + (k - 1) * kMmSub, [&](int n) {
-                if (n < kMmSteps) af_next[n] = k + 1 < kMmBT ? operand(cur, k + 1, n) : operand(nxt, 0, n);
+                if (k + 1 < kMmBT) refill(afn, n, cur, k + 1); else refill(afn, n, nxt, 0);
                 if (n >= 4) {
                     // output dword n - 4 of this thread's row of block k of tile T + 2 (the empty statement keeps the
                     // two instructions in their slice: the compiler would otherwise gather them in front of the write)
@@ -551,13 +557,13 @@ __global__ __launch_bounds__(kMmBlock, 2) void match_mfma_kernel(MatchArgs a) {
     for (int k = 0; k < kMmBT; k++) {
         v16f (&acc)[kMmNB] = (k & 1) ? acc1 : acc0;
         v16f (&prev)[kMmNB] = (k & 1) ? acc0 : acc1;
-        const v4i (&af)[kMmSteps] = (k & 1) ? af1 : af0;
-        v4i (&af_next)[kMmSteps] = (k & 1) ? af0 : af1;
+        const v4i (&af)[kMmSteps] = (kMeta && (k & 1)) ? af1 : af0;
+        v4i (&afn)[kMmSteps] = (kMeta && !(k & 1)) ? af1 : af0;
         if (k > 0) gate_tail(prev, rows_left - (k - 1) * kMmSub);
         const int mbp = k == 0 ? mb_prev : mb, kp = k == 0 ? kMmBT - 1 : k - 1, bprev = blockno + (k - 1) * kMmSub;
         if (k == 0 || rows_left > k * kMmSub) {
             run_block(acc, prev, af, mbp, kp, bprev, [&](int n) {
-                if (n < kMmSteps && k + 1 < kMmBT) af_next[n] = operand(cur, k + 1, n);
+                if (k + 1 < kMmBT) refill(afn, n, cur, k + 1);
             });
         } else {
             // an empty block: only the block before it is left to finish; its own accumulators all fail
