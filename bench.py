@@ -85,7 +85,9 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="frames", choices=["frames", "stream4k", "projection"],
                     help="frames: 640x480 / 2000 features (default, the headline line); stream4k: 3840x2160 stream; "
                          "projection: 1241x376, 20000 map points in a 50 px window")
-    ap.add_argument("--stream-frames", type=int, default=300)
+    ap.add_argument("--stream-frames", type=int, default=1000)
+    ap.add_argument("--stream-batches", default="1,2,4",
+                    help="stream4k: frames queued per launch sequence, one timed run each; `value` is the last one's")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a HIP graph replay")
     ap.add_argument("--graph-order", default="late", choices=["early", "late"],
                     help="early: both graphs (batch, single frame) are captured and instantiated before either is "
@@ -450,7 +452,7 @@ def run_frames(args):
                           "vs_gates_off": round(dt / tg, 4),
                           "matches_per_frame": round(float(d_nout.cpu().numpy().mean()), 1)}
         # ---- frames arriving in pinned host memory: H2D, compute and D2H overlapped ----
-        extra["host_pipelined"] = run_host_pipelined(args, torch, ranks, ex, m, frames, dev, world)
+        extra["host_pipelined"] = run_host_pipelined(args, torch, ranks, frames, world)
 
     line = {
         "metric": "frames/s ORB extract+match @640x480 2k feats",
@@ -499,66 +501,34 @@ def run_frames(args):
     return 0
 
 
-def run_host_pipelined(args, torch, ranks, ex, m, frames, dev, world):
-    """The frame step with inputs in pinned host memory and results copied back: two slots,
-    three streams (H2D of batch i+1, compute of batch i, D2H of batch i-1 overlap)."""
+def run_host_pipelined(args, torch, ranks, frames, world):
+    """The frame step with inputs in pinned host memory and results copied back, through the library's C++
+    pipeline (slam_amd_pipeline_*): three slots of one batch each, three streams (upload of batch i + 1,
+    compute of batch i, download of batch i - 1 overlap).  The slots' input buffers are filled once, as a
+    camera writing by DMA would leave them; a step = `batch` frames handed in and submitted."""
+    from slam_amd import capi
     W, H, B, CAP = args.width, args.height, args.batch, args.capacity
-    KP, DM = 28, 16
-    u8 = torch.uint8
-    h_img = [torch.from_numpy(frames.copy()).pin_memory() for _ in range(2)]
-    d_img = [torch.empty((B, H, W), dtype=u8, device=dev) for _ in range(2)]
-    d_kp = [torch.zeros(B * CAP * KP, dtype=u8, device=dev) for _ in range(2)]
-    d_desc = [torch.zeros(B * CAP * 32, dtype=u8, device=dev) for _ in range(2)]
-    d_cnt = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
-    d_out = [torch.zeros(B * CAP * DM, dtype=u8, device=dev) for _ in range(2)]
-    d_nout = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
-    h_kp = [torch.empty(B * CAP * KP, dtype=u8).pin_memory() for _ in range(2)]
-    h_desc = [torch.empty(B * CAP * 32, dtype=u8).pin_memory() for _ in range(2)]
-    h_out = [torch.empty(B * CAP * DM, dtype=u8).pin_memory() for _ in range(2)]
-    h_cnt = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(2)]
-    h_nout = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(2)]
-    s_copy, s_comp, s_back = (torch.cuda.Stream(device=dev) for _ in range(3))
-    ev_in = [torch.cuda.Event() for _ in range(2)]
-    ev_done = [torch.cuda.Event() for _ in range(2)]
-    ev_out = [torch.cuda.Event() for _ in range(2)]
+    pipe = capi.Pipeline(capi.orb_params(nfeatures=args.nfeatures), W, H, CAP, depth=3, batch=B, device=ranks.local_rank)
     n = {"i": 0}
 
-    def submit():
-        i = n["i"]; n["i"] += 1
-        s, p = i % 2, (i - 1) % 2
-        with torch.cuda.stream(s_copy):
-            if i >= 2:
-                s_copy.wait_event(ev_done[s])       # the slot's image was last read by batch i-2
-            d_img[s].copy_(h_img[s], non_blocking=True)
-            ev_in[s].record(s_copy)
-        with torch.cuda.stream(s_comp):
-            s_comp.wait_event(ev_in[s])
-            if i >= 2:
-                s_comp.wait_event(ev_out[s])        # the slot's results of batch i-2 have left
-            st = s_comp.cuda_stream
-            kp_p, desc_p, cnt_p = d_kp[s].data_ptr(), d_desc[s].data_ptr(), d_cnt[s].data_ptr()
-            ex.extract_batch_async(d_img[s], B, H * W, W, kp_p, desc_p, cnt_p, CAP, st)
-            # previous frame of this batch = last frame of the batch before (other slot)
-            m.frame_match_chain_async(B, d_desc[p].data_ptr() + (B - 1) * CAP * 32, d_kp[p].data_ptr() + (B - 1) * CAP * KP,
-                                      d_cnt[p].data_ptr() + 4 * (B - 1), desc_p, kp_p, CAP, cnt_p, d_out[s], d_nout[s],
-                                      max_dist=300.0, area=-1.0, max_level=-1, stream=st)
-            ev_done[s].record(s_comp)
-        with torch.cuda.stream(s_back):
-            s_back.wait_event(ev_done[s])
-            h_cnt[s].copy_(d_cnt[s], non_blocking=True)
-            h_kp[s].copy_(d_kp[s], non_blocking=True)
-            h_desc[s].copy_(d_desc[s], non_blocking=True)
-            h_nout[s].copy_(d_nout[s], non_blocking=True)
-            h_out[s].copy_(d_out[s], non_blocking=True)
-            ev_out[s].record(s_back)
+    def submit(fill=False):
+        for k in range(B):
+            i = n["i"]; n["i"] += 1
+            buf = pipe.input(i)
+            if fill:
+                buf[...] = frames[k]
+            pipe.submit(i)
 
-    for _ in range(4):
-        submit()
+    for _ in range(3):
+        submit(fill=True)
+    submit()
     t = statistics.median(timed_repeats(ranks, submit, args.steps, min(3, args.repeats)))
-    torch.cuda.synchronize()
+    kp, desc, mt = pipe.result(n["i"] - 1)
+    pipe.close()
     return {"frames_per_s": round(world * B * args.steps / t, 2), "ms_per_step": round(t / args.steps * 1e3, 4),
-            "h2d_bytes_per_step": B * W * H, "d2h_bytes_per_step": B * CAP * (KP + 32 + DM) + 8 * B,
-            "launch_mode": "eager, 3 streams, 2 slots, pinned host buffers"}
+            "h2d_bytes_per_step": B * W * H, "d2h_bytes_per_step": B * CAP * (28 + 32 + 16) + 8 * B,
+            "keypoints_last_frame": int(len(kp)), "matches_last_frame": int(len(mt)),
+            "launch_mode": "slam_amd_pipeline_* (C++ host): eager, 3 streams, 3 slots of one batch, pinned host buffers"}
 
 
 def pmc_counters(kernel, batch, width, height):
@@ -700,56 +670,79 @@ def run_rehearsal(args):
 
 
 def run_stream4k(args):
-    """4K stream configuration: 3840x2160 stream, 10000 features, extract + match vs previous frame,
-    frames arriving in pinned host memory, H2D / compute / D2H overlapped on three streams."""
+    """4K stream configuration: 3840x2160 stream, 10000 features, extract + match vs previous frame.  Two legs per
+    batch size (frames queued per launch sequence): frames resident in HBM, results left there (`value`); and frames
+    arriving in pinned host memory through the library's C++ pipeline (slam_amd_pipeline_*), upload / compute /
+    download overlapped on three streams, results read back on the host."""
     import torch
     from slam_amd import capi, synth
-    from slam_amd.stream import FramePipeline
     W, H, NF, CAP = 3840, 2160, 10000, 12288
     n = args.stream_frames
-    seq = synth.frame_sequence(W, H, 4, seed=1)
-    pipe = FramePipeline(torch, W, H, capi.orb_params(nfeatures=NF), CAP, depth=4)
-    for i in range(pipe.depth):                 # a producer would write here; pre-filled once
-        pipe.h_img[i].numpy()[...] = seq[i % len(seq)]
-    for i in range(8):                          # warm-up
-        pipe.slot_image(i); pipe.submit(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(8, 8 + n):
-        pipe.slot_image(i)                      # waits until the slot's previous results are out
-        pipe.submit(i)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kp, desc, matches = pipe.result(8 + n - 1)
-    # the same work with the frames already resident in HBM and no result copies
-    pipe2 = FramePipeline(torch, W, H, capi.orb_params(nfeatures=NF), CAP, depth=4, copy_results=False)
-    d_frames = [torch.from_numpy(seq[i % len(seq)]).cuda() for i in range(4)]
+    batches = [int(b) for b in args.stream_batches.split(",")]
+    seq = synth.frame_sequence(W, H, 8, seed=1)
+    params = capi.orb_params(nfeatures=NF)
+    dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
+    legs = []
+    for B in batches:
+        steps = max(1, n // B)
+        # ---- pipelined: the ring's input buffers are written once (a camera's DMA would keep writing there) ----
+        pipe = capi.Pipeline(params, W, H, CAP, depth=4, batch=B)
+        ring = 4 * B
+        for i in range(2 * ring):                                 # fill + warm-up
+            buf = pipe.input(i)
+            if i < ring:
+                buf[...] = seq[i % len(seq)]
+            pipe.submit(i)
+        pipe.result(2 * ring - 1, copy=False)
+        t0 = time.perf_counter()
+        for i in range(2 * ring, 2 * ring + steps * B):
+            pipe.input(i)                                         # waits until the slot's previous results are out
+            pipe.submit(i)
+        kp, desc, matches = pipe.result(2 * ring + steps * B - 1)
+        dt = time.perf_counter() - t0
+        pipe.close()
+        # ---- resident: the same launches on frames already in HBM, no result copies ----
+        ex = capi.Extractor(params, W, H, max_batch=B, max_keypoints=CAP)
+        m = capi.Matcher()
+        m.reserve(B, CAP, CAP)
+        d_img = [torch.from_numpy(np.stack([seq[(s * B + k) % len(seq)] for k in range(B)])).to(dev) for s in range(2)]
+        d_kp = [torch.zeros(B * CAP * 28, dtype=torch.uint8, device=dev) for _ in range(2)]
+        d_desc = [torch.zeros(B * CAP * 32, dtype=torch.uint8, device=dev) for _ in range(2)]
+        d_cnt = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+        d_out = torch.zeros(B * CAP * 16, dtype=torch.uint8, device=dev)
+        d_nout = torch.zeros(B, dtype=torch.int32, device=dev)
 
-    def resident_step(i):
-        s_, p_ = i % 4, (i - 1) % 4
-        pipe2.ex.extract_batch_async(d_frames[s_], 1, 0, W, pipe2.d_kp[s_], pipe2.d_desc[s_], pipe2.d_cnt[s_], CAP, st)
-        pipe2.m.frame_match_async(pipe2.d_desc[p_], pipe2.d_kp[p_], CAP, pipe2.d_cnt[p_], pipe2.d_desc[s_],
-                                  pipe2.d_kp[s_], CAP, pipe2.d_cnt[s_], pipe2.d_match[s_], pipe2.d_nmatch[s_],
-                                  max_dist=300.0, area=-1.0, max_level=-1, stream=st)
-    for i in range(8):
-        resident_step(i)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(8, 8 + n):
-        resident_step(i)
-    torch.cuda.synchronize()
-    dt2 = time.perf_counter() - t1
-    pipe.close(); pipe2.close()
+        def resident_step(i):
+            s_, p_ = i % 2, (i - 1) % 2
+            ex.extract_batch_async(d_img[s_], B, H * W, W, d_kp[s_].data_ptr(), d_desc[s_].data_ptr(), d_cnt[s_].data_ptr(), CAP, st)
+            m.frame_match_chain_async(B, d_desc[p_].data_ptr() + (B - 1) * CAP * 32, d_kp[p_].data_ptr() + (B - 1) * CAP * 28,
+                                      d_cnt[p_].data_ptr() + 4 * (B - 1), d_desc[s_].data_ptr(), d_kp[s_].data_ptr(), CAP,
+                                      d_cnt[s_].data_ptr(), d_out, d_nout, max_dist=300.0, area=-1.0, max_level=-1, stream=st)
+        for i in range(8):
+            resident_step(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(8, 8 + steps):
+            resident_step(i)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        ex.close(); m.close()
+        legs.append({"batch": B, "frames": steps * B, "frames_per_s_resident": round(steps * B / dt2, 2),
+                     "frames_per_s_pipelined": round(steps * B / dt, 2),
+                     "ms_per_frame_resident": round(dt2 / (steps * B) * 1e3, 4),
+                     "ms_per_frame_pipelined": round(dt / (steps * B) * 1e3, 4),
+                     "h2d_GBps_pipelined": round(steps * B * W * H / dt / 1e9, 2),
+                     "keypoints_last_frame": int(len(kp)), "matches_last_frame": int(len(matches))})
+    last = legs[-1]
     print(json.dumps({
         "metric": "frames/s ORB extract+match @3840x2160 10k feats, pipelined stream", "unit": "frames/s",
-        "value": round(n / dt2, 2), "value_including_h2d_and_d2h": round(n / dt, 2),
-        "n_gpus": 1, "steps": n, "ms_per_frame_resident": round(dt2 / n * 1e3, 4),
-        "ms_per_frame_pipelined": round(dt / n * 1e3, 4),
+        "value": last["frames_per_s_resident"], "value_including_h2d_and_d2h": last["frames_per_s_pipelined"],
+        "n_gpus": 1, "steps": last["frames"], "by_batch": legs,
         "h2d_bytes_per_frame": W * H, "d2h_bytes_per_frame": CAP * (28 + 32 + 16) + 8,
-        "keypoints_last_frame": len(kp), "matches_last_frame": len(matches),
-        "config": {"workload": "3840x2160 synthetic stream, 10000 ORB features, match vs previous frame, "
-                               "frames in pinned host memory, 3 streams, 4 slots"},
+        "config": {"workload": "3840x2160 synthetic stream, 10000 ORB features, match vs previous frame; `value`: frames "
+                               "resident in HBM, %d per launch sequence; pipelined: frames in pinned host memory through "
+                               "slam_amd_pipeline_* (C++ host), 3 streams, 4 slots of %d frame(s)" % (last["batch"], last["batch"])},
         "data": "synthetic", "dtype": "u8"}), flush=True)
     return 0
 

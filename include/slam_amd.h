@@ -378,11 +378,24 @@ int slam_amd_outlier_flags(slam_amd_matcher* m, const float* xyz, const slam_amd
  *   slam_amd_pipeline_result(p, i, ...)           wait for frame i; pointers into pinned host
  *                                                 buffers, valid until _input(p, i + depth)
  * Matches are frameMatch(frame i - 1, frame i, {}, max_dist, area, max_level): queries are the
- * previous frame's keypoints (none for frame 0). */
+ * previous frame's keypoints (none for frame 0).
+ * create_batched: a slot collects `batch` (1..64) frames and queues them as one upload, one extraction
+ * launch sequence, one chained matching call and one download when the last of them is submitted -- a
+ * single large frame leaves the chip idle between its short launches, a few per launch fill it; the price
+ * is the batch's latency.  Frames are still numbered, filled, submitted and read one by one;
+ * slam_amd_pipeline_flush queues an incomplete batch (end of the stream, or a producer that stalls), and
+ * _result of a frame whose batch is neither complete nor flushed is an error, not a wait.  Results live
+ * until depth - 1 more batches are queued.  create = create_batched with batch 1.
+ * A submit or flush that fails after part of its work was queued drains the three streams and leaves
+ * the pipeline unusable except for _result of earlier frames and _destroy. */
 typedef struct slam_amd_pipeline slam_amd_pipeline;
 int slam_amd_pipeline_create(const slam_amd_orb_params* params, int width, int height, int capacity,
                              int depth, int device, float max_dist, float area, int max_level,
                              slam_amd_pipeline** out);
+int slam_amd_pipeline_create_batched(const slam_amd_orb_params* params, int width, int height, int capacity,
+                                     int depth, int batch, int device, float max_dist, float area, int max_level,
+                                     slam_amd_pipeline** out);
+int slam_amd_pipeline_flush(slam_amd_pipeline* p);
 int slam_amd_pipeline_destroy(slam_amd_pipeline* p);
 int slam_amd_pipeline_input(slam_amd_pipeline* p, long long frame, uint8_t** host_image, int* row_stride);
 int slam_amd_pipeline_submit(slam_amd_pipeline* p, long long frame);

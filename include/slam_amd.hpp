@@ -420,11 +420,13 @@ public:
         const DMatch* matches = nullptr;       // frameMatch(previous frame, this frame): queryIdx = previous frame's keypoint
         int nMatches = 0;
     };
+    // batch > 1: frames are queued `batch` at a time (see slam_amd_pipeline_create_batched); flush() queues an
+    // incomplete batch
     FramePipeline(const slam_amd_orb_params& params, int width, int height, int capacity, int depth = 3,
-                  float maximumDistance = 300, float areaSize = -1, int maxLevel = -1, int device = 0)
+                  float maximumDistance = 300, float areaSize = -1, int maxLevel = -1, int device = 0, int batch = 1)
         : width_(width), height_(height) {
-        check(slam_amd_pipeline_create(&params, width, height, capacity, depth, device, maximumDistance, areaSize,
-                                       maxLevel, &p_));
+        check(slam_amd_pipeline_create_batched(&params, width, height, capacity, depth, batch, device, maximumDistance,
+                                               areaSize, maxLevel, &p_));
     }
     FramePipeline(const FramePipeline&) = delete;
     FramePipeline& operator=(const FramePipeline&) = delete;
@@ -450,6 +452,7 @@ public:
         check(slam_amd_pipeline_submit(p_, next_));
         return next_++;
     }
+    void flush() { check(slam_amd_pipeline_flush(p_)); }
     // Blocks until frame `index` is done.  The pointers stay valid until `depth` more frames were pushed.
     Result result(long long index) const {
         Result r;

@@ -42,7 +42,7 @@ EXPORTS = [
     "slam_amd_frontend_create", "slam_amd_frontend_destroy", "slam_amd_frontend_output_size",
     "slam_amd_frontend_run_async", "slam_amd_frontend_run", "slam_amd_linear_taps",
     "slam_amd_pipeline_create", "slam_amd_pipeline_destroy", "slam_amd_pipeline_input", "slam_amd_pipeline_submit",
-    "slam_amd_pipeline_result",
+    "slam_amd_pipeline_result", "slam_amd_pipeline_create_batched", "slam_amd_pipeline_flush",
     "slam_amd_prof_enable", "slam_amd_prof_collect", "slam_amd_prof_stage_name",
     "slam_amd_sincos_f32", "slam_amd_fast_atan2", "slam_amd_linear_exact_coeffs", "slam_amd_debug_pyramid_plan",
 ]
@@ -128,6 +128,15 @@ def lib():
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
             C.c_int, C.c_double, C.c_void_p]
         l.slam_amd_linear_exact_coeffs.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        l.slam_amd_pipeline_create_batched.argtypes = [
+            C.POINTER(OrbParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+            C.POINTER(C.c_void_p)]
+        l.slam_amd_pipeline_destroy.argtypes = [C.c_void_p]
+        l.slam_amd_pipeline_input.argtypes = [C.c_void_p, C.c_longlong, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        l.slam_amd_pipeline_submit.argtypes = [C.c_void_p, C.c_longlong]
+        l.slam_amd_pipeline_flush.argtypes = [C.c_void_p]
+        l.slam_amd_pipeline_result.argtypes = [C.c_void_p, C.c_longlong, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         l.slam_amd_prof_stage_name.restype = C.c_char_p
         l.slam_amd_prof_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib = l
@@ -293,6 +302,52 @@ def device_count():
     n = C.c_int(0)
     check(lib().slam_amd_device_count(C.byref(n)))
     return n.value
+
+
+class Pipeline:
+    """Owner of a slam_amd_pipeline handle: the C++ host of the streaming configuration (frames in pinned
+    host memory; upload, extract + match against the previous frame and download on three HIP streams over a
+    ring of `depth` slots of `batch` frames each)."""
+
+    def __init__(self, params, width, height, capacity, depth=3, batch=1, device=0, max_dist=300.0, area=-1.0, max_level=-1):
+        self._h = C.c_void_p()
+        self.width, self.height, self.capacity, self.depth, self.batch = width, height, capacity, depth, batch
+        check(lib().slam_amd_pipeline_create_batched(C.byref(params), width, height, capacity, depth, batch, device,
+                                                     max_dist, area, int(max_level), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().slam_amd_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def input(self, frame):
+        """The pinned host buffer of frame `frame` (the next one to submit) as a (height, width) uint8 array;
+        waits until the slot is free."""
+        buf, stride = C.c_void_p(), C.c_int(0)
+        check(lib().slam_amd_pipeline_input(self._h, frame, C.byref(buf), C.byref(stride)))
+        raw = (C.c_uint8 * (self.height * stride.value)).from_address(buf.value)
+        return np.frombuffer(raw, dtype=np.uint8).reshape(self.height, stride.value)[:, :self.width]
+
+    def submit(self, frame):
+        check(lib().slam_amd_pipeline_submit(self._h, frame))
+
+    def flush(self):
+        check(lib().slam_amd_pipeline_flush(self._h))
+
+    def result(self, frame, copy=True):
+        """Waits for frame `frame`: (keypoints, descriptors [n][32], matches against the frame before)."""
+        kp, desc, mt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        n, nm = C.c_int(0), C.c_int(0)
+        check(lib().slam_amd_pipeline_result(self._h, frame, C.byref(kp), C.byref(desc), C.byref(n), C.byref(mt), C.byref(nm)))
+
+        def view(addr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype)
+            raw = (C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(addr)
+            a = np.frombuffer(raw, dtype=dtype)
+            return a.copy() if copy else a
+        return (view(kp.value, n.value, KEYPOINT_DTYPE), view(desc.value, n.value * 32, np.uint8).reshape(-1, 32),
+                view(mt.value, nm.value, DMATCH_DTYPE))
 
 
 class Extractor:

@@ -307,7 +307,12 @@ static int make_pyramid_plan(const PyrGeom& g, HostPyramidPlan& plan) {
     // padded by replicating the last entry so that whole dwords of a row can be produced
     std::vector<std::vector<int32_t>> xo(g.nlevels), yo(g.nlevels);
     int ws[kMaxLevels], hs[kMaxLevels];
-    for (int l = 0; l < g.nlevels; l++) { ws[l] = g.lv[l].w; hs[l] = g.lv[l].h; }
+    for (int l = 0; l < g.nlevels; l++) {
+        ws[l] = g.lv[l].w; hs[l] = g.lv[l].h;
+        // the tile spans (PyrSpan) hold coordinates of a level, rounded up to whole dwords, in 16-bit signed fields
+        if (((ws[l] + 3) & ~3) > 32767 || ((hs[l] + 3) & ~3) > 32767)
+            SA_FAIL(SLAM_AMD_ERR_ARG, "image too large: a pyramid level may be at most 32764 pixels wide and high");
+    }
     constexpr int kPad = 8;
     for (int l = 1; l < g.nlevels; l++) {
         const int sw = ws[l - 1], sh = hs[l - 1], dw = ws[l], dh = hs[l];

@@ -417,8 +417,8 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         const unsigned srow = (code * 1821u) >> 17;               // code / 72 for code < 40 * 72
         s_sc[code - 6u * srow - (unsigned)(3 * kScPitch + 3)] = (uint8_t)(best - 1);   // (srow - 3) * 66 + (column - 3)
     }
-    // Blur, vertical pass: 7 taps 18 34 49 55 49 34 18 (8.8 fixed point, sum 256) down the
-    // columns of the split tile; the result fits 16 bits per pixel.  Item = (column group and
+    // Blur, vertical pass: 7 taps 18 34 49 55 49 34 18 (8.8 fixed point; each is rounded on its own and
+    // they add up to 257, not 256) down the columns of the split tile; the result fits 16 bits per pixel.  Item = (column group and
     // parity, 4 output rows): 36 x 8 items.
     for (int i = tid; i < 2 * kImgDw * (kFastTileH / 4); i += 256) {
         const int chunk = i / (2 * kImgDw), cp = i - chunk * (2 * kImgDw);

@@ -31,6 +31,7 @@ struct slam_amd_pair_shard {
     ncclComm_t comm = nullptr;
     hipStream_t s_comm = nullptr;
     std::vector<hipEvent_t> ev;              // chunk computed
+    hipEvent_t ev_sent = nullptr;            // everything queued on s_comm so far (the previous run's sends and receives)
     uint32_t* rows = nullptr;                // [per][n_per] this rank's results (rank 0 with world 1: the result itself)
     uint32_t* gathered = nullptr;            // rank 0, world > 1: [world][per][n_per]
 };
@@ -71,6 +72,7 @@ extern "C" int slam_amd_pair_shard_destroy(slam_amd_pair_shard* s) {
     if (s->s_comm) (void)hipStreamSynchronize(s->s_comm);
     if (s->comm) (void)ncclCommDestroy(s->comm);
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+    if (s->ev_sent) (void)hipEventDestroy(s->ev_sent);
     if (s->s_comm) (void)hipStreamDestroy(s->s_comm);
     if (s->rows) (void)hipFree(s->rows);
     if (s->gathered) (void)hipFree(s->gathered);
@@ -102,6 +104,7 @@ extern "C" int slam_amd_pair_shard_create(slam_amd_matcher* m, int device, const
         s->ev.resize((size_t)chunks);
         for (auto& e : s->ev)
             if ((rc = hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"))) return fail(rc);
+        if ((rc = hip(hipEventCreateWithFlags(&s->ev_sent, hipEventDisableTiming), "hipEventCreate"))) return fail(rc);
         ncclUniqueId u;
         memcpy(u.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
         ncclResult_t r = ncclCommInitRank(&s->comm, world, u, rank);
@@ -120,6 +123,12 @@ extern "C" int slam_amd_pair_shard_run(slam_amd_pair_shard* s, const uint8_t* d_
     SA_HIP(hipSetDevice(s->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool exchange = s->world > 1 && limit_rows < 0;   // a limited run is a warm-up: nothing is sent
+    // this run overwrites the rows the run before may still be sending (or, on rank 0, copying into the
+    // gathered table): the compute stream waits for whatever the communication stream holds
+    if (s->s_comm) {
+        SA_HIP(hipEventRecord(s->ev_sent, s->s_comm));
+        SA_HIP(hipStreamWaitEvent(st, s->ev_sent, 0));
+    }
     for (int c = 0; c < s->chunks; c++) {
         int r0, r1;
         slam_amd_pair_shard_chunk(s->per, s->chunks, c, &r0, &r1);

@@ -33,6 +33,21 @@ struct Point3f {
     Point3f(float x, float y, float z) : x(x), y(y), z(z) {}
 };
 
+struct Point { int x = 0, y = 0; Point() {} Point(int x, int y) : x(x), y(y) {} };
+struct Size {
+    int width = 0, height = 0;
+    Size() {}
+    Size(int w, int h) : width(w), height(h) {}
+    bool operator==(const Size& o) const { return width == o.width && height == o.height; }
+};
+struct Rect {
+    int x = 0, y = 0, width = 0, height = 0;
+    Rect() {}
+    Rect(int x, int y, int w, int h) : x(x), y(y), width(w), height(h) {}
+};
+Rect operator&(const Rect& a, const Rect& b);   // declared only
+struct Scalar { double val[4] = {0, 0, 0, 0}; Scalar() {} Scalar(double v0) { val[0] = v0; } };
+
 struct KeyPoint {
     Point2f pt;
     float size = 0, angle = -1, response = 0;
@@ -54,6 +69,10 @@ public:
     uint8_t* data = nullptr;
     Mat() {}
     Mat(int r, int c, int type) { create(r, c, type); }
+    Mat(int r, int c, int type, const Scalar& fill);   // declared only
+    Size size() const { return Size(cols, rows); }
+    uint8_t* ptr(int r = 0) { return data + static_cast<size_t>(r) * step; }
+    const uint8_t* ptr(int r = 0) const { return data + static_cast<size_t>(r) * step; }
     static size_t elem(int type) { return type == CV_8U ? 1 : type == CV_32F ? 4 : type == CV_64F ? 8 : type == CV_8UC3 ? 3 : 0; }
     void create(int r, int c, int type) {
         type_ = type; rows = r; cols = c; step = static_cast<size_t>(c) * elem(type);
@@ -86,6 +105,18 @@ private:
     int type_ = CV_8U;
     std::shared_ptr<std::vector<uint8_t>> store_;
 };
+
+// ---- declarations without definitions: enough for a syntax check of code written against OpenCV, never linked ----
+class _InputArray { public: _InputArray(); _InputArray(const Mat&); };
+class _OutputArray : public _InputArray { public: _OutputArray(); _OutputArray(Mat&); };
+class _InputOutputArray : public _OutputArray { public: _InputOutputArray(); _InputOutputArray(Mat&); };
+typedef const _InputArray& InputArray;
+typedef const _OutputArray& OutputArray;
+typedef const _InputOutputArray& InputOutputArray;
+InputOutputArray noArray();
+enum NormTypes { NORM_L2 = 4, NORM_HAMMING = 6 };
+void randn(InputOutputArray dst, const Scalar& mean, const Scalar& stddev);
+void add(InputArray a, InputArray b, OutputArray dst, InputArray mask, int dtype = -1);
 
 }  // namespace cv
 

@@ -19,6 +19,9 @@ public:
         o->fastThreshold = fastThreshold;
         return o;
     }
+    // declared only (syntax checks of code written against OpenCV)
+    void detectAndCompute(InputArray image, InputArray mask, std::vector<KeyPoint>& keypoints, OutputArray descriptors,
+                          bool useProvidedKeypoints = false);
     int getMaxFeatures() const { return nfeatures; }
     double getScaleFactor() const { return scaleFactor; }
     int getNLevels() const { return nlevels; }
@@ -37,6 +40,8 @@ private:
 class BFMatcher {
 public:
     enum { BRUTEFORCE_HAMMING = 4 };
+    BFMatcher() {}
+    explicit BFMatcher(int normType, bool crossCheck = false) : norm(normType), cross(crossCheck) {}
     static Ptr<BFMatcher> create(int normType = BRUTEFORCE_HAMMING, bool crossCheck = false) {
         Ptr<BFMatcher> m(new BFMatcher);
         m->norm = normType; m->cross = crossCheck;

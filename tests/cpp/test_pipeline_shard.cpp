@@ -1,7 +1,8 @@
 // C++ host components of the streaming and the multi-GPU configuration, on one GPU:
 //   slam_amd::FramePipeline  three HIP streams over a ring of pinned slots; every frame's
 //                            keypoints, descriptors and matches against the previous frame must
-//                            equal the sequential CPU oracle's
+//                            equal the sequential CPU oracle's -- at 320 x 240 one frame at a time with the
+//                            gates on, and at 3840 x 2160 / 10000 features two frames per launch sequence
 //   slam_amd::PairShard      the RCCL pair shard with a world of one rank (no communicator): all
 //                            pairs of a small keyframe store against the oracle, and the share /
 //                            chunk arithmetic for larger worlds
@@ -26,13 +27,13 @@ static int g_fail = 0;
 static unsigned rng_state = 12345;
 static unsigned rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
 
-static std::vector<uint8_t> make_scene(int w, int h, int shift) {
+static std::vector<uint8_t> make_scene(int w, int h, int shift, int blobs = 500) {
     std::vector<uint8_t> img((size_t)w * h);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++)
             img[(size_t)y * w + x] = (uint8_t)(60 + 40 * std::sin((x + shift) * 0.05) + 30 * std::cos(y * 0.07));
     rng_state = 777;
-    for (int i = 0; i < 500; i++) {
+    for (int i = 0; i < blobs; i++) {
         int cx = (int)(rnd() % w) + shift, cy = (int)(rnd() % h), r = 3 + (int)(rnd() % 12);
         uint8_t v = (uint8_t)(rnd() % 256);
         for (int y = std::max(0, cy - r); y < std::min(h, cy + r); y++)
@@ -81,6 +82,48 @@ static void test_pipeline() {
     bool threw = false;
     try { pipe.result(0); } catch (const slam_amd::Error&) { threw = true; }
     EXPECT(threw, "a slot that was reused must not hand out stale results");
+}
+
+// The streaming configuration at its real size: 3840 x 2160 frames, 10000 features, two frames per launch
+// sequence, five frames (the last batch is incomplete and flushed), gates off as the stream benchmark runs it.
+static void test_pipeline_4k() {
+    const int W = 3840, H = 2160, NF = 10000, CAP = 12288, N = 5;
+    slam_amd_orb_params p;
+    slam_amd_default_orb_params(&p);
+    p.nfeatures = NF;
+    slam_amd::FramePipeline pipe(p, W, H, CAP, 3, 300, -1, -1, 0, 2);
+    orc_params op; orc_default_params(&op); op.nfeatures = NF;
+    std::vector<std::vector<uint8_t>> frames;
+    for (int i = 0; i < N; i++) frames.push_back(make_scene(W, H, 5 * i, 40000));
+    for (int i = 0; i < N; i++) {
+        slam_amd::Image8 v; v.data = frames[i].data(); v.cols = W; v.rows = H; v.step = W;
+        EXPECT(pipe.push(v) == i, "frame index");
+    }
+    bool threw = false;
+    try { pipe.result(N - 1); } catch (const slam_amd::Error&) { threw = true; }
+    EXPECT(threw, "a frame of an incomplete batch has no result before flush()");
+    pipe.flush();
+    std::vector<orc_keypoint> pk, ck(CAP);
+    std::vector<uint8_t> pd, cd((size_t)CAP * 32);
+    for (int j = 0; j < N; j++) {
+        const slam_amd::FramePipeline::Result r = pipe.result(j);
+        int cn = 0;
+        orc_detect_and_compute(&op, frames[j].data(), W, H, W, ck.data(), cd.data(), CAP, &cn);
+        EXPECT(r.n == cn && cn > 3000, "4K frame %d: %d keypoints vs %d", j, r.n, cn);
+        EXPECT(std::memcmp(r.keypoints, ck.data(), (size_t)cn * 28) == 0, "4K frame %d keypoints", j);
+        EXPECT(std::memcmp(r.descriptors, cd.data(), (size_t)cn * 32) == 0, "4K frame %d descriptors", j);
+        if (j > 0) {
+            std::vector<orc_dmatch> ref(pk.size());
+            int rn = 0;
+            orc_match_gated(pd.data(), pk.data(), (int)pk.size(), cd.data(), ck.data(), cn, 300.f, -1.f, -1, ref.data(), &rn);
+            EXPECT(r.nMatches == rn && rn > 1000, "4K frame %d: %d matches vs %d", j, r.nMatches, rn);
+            EXPECT(std::memcmp(r.matches, ref.data(), (size_t)rn * 16) == 0, "4K frame %d matches", j);
+        } else {
+            EXPECT(r.nMatches == 0, "frame 0 has no previous frame");
+        }
+        pk.assign(ck.begin(), ck.begin() + cn);
+        pd.assign(cd.begin(), cd.begin() + (size_t)cn * 32);
+    }
 }
 
 static void test_pair_shard() {
@@ -158,6 +201,7 @@ int main() {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { printf("no GPU\n"); return 77; }
     try {
         test_pipeline();
+        test_pipeline_4k();
         test_pair_shard();
     } catch (const std::exception& e) {
         printf("exception: %s\n", e.what());

@@ -25,6 +25,13 @@ def test_dropin_header_parses_against_the_reference_headers():
     assert "checked against" in note or "skipped" in note
 
 
+def test_opencv_diff_tool_parses():
+    """CPU: tests/cpp/opencv_diff.cpp (the tool that compares the library with OpenCV itself, built only where
+    OpenCV is installed) parses and type-checks against the declarations of the test-only stand-in."""
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "cpp"), "opencv_diff_syntax.ok"], stdout=subprocess.DEVNULL)
+    assert "parses" in open(os.path.join(HERE, "cpp", "opencv_diff_syntax.ok")).read()
+
+
 @pytest.mark.gpu
 def test_cpp_host_layer_matches_oracle():
     assert os.path.exists(EXE), "build it first: make -C tests/cpp (or __graft_entry__.build())"
@@ -55,5 +62,5 @@ def test_cpp_frame_pipeline_and_pair_shard():
     """slam_amd::FramePipeline (three streams, pinned ring) against the sequential oracle, and
     slam_amd::PairShard (the RCCL pair shard) with a world of one rank against the oracle."""
     assert os.path.exists(EXE_PIPE), "build it first: make -C tests/cpp (or __graft_entry__.build())"
-    r = subprocess.run([EXE_PIPE], capture_output=True, text=True, timeout=180)
+    r = subprocess.run([EXE_PIPE], capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -442,14 +442,22 @@ def test_duplicate_pairs_vs_oracle(oracle, capi):
 
 
 # ------------------------------------------------------------------ pipeline ----
-def test_frame_pipeline_matches_sequential_oracle(oracle, capi):
-    """Three-stream pipeline (H2D / extract + match / D2H) over a short sequence."""
-    torch = _torch()
+@pytest.mark.parametrize("batch", [1, 3])
+def test_frame_pipeline_matches_sequential_oracle(oracle, capi, batch):
+    """The library's three-stream pipeline (H2D / extract + match / D2H) over a short sequence, frames queued one
+    at a time and three at a time (7 frames: the last batch is incomplete and flushed)."""
     from slam_amd.stream import FramePipeline
     W, H, NF = 320, 240, 400
     frames = synth.frame_sequence(W, H, 7, seed=5)
-    pipe = FramePipeline(torch, W, H, capi.orb_params(nfeatures=NF), 2048, depth=3,
+    pipe = FramePipeline(W, H, capi.orb_params(nfeatures=NF), 2048, depth=3, batch=batch,
                          max_dist=300.0, area=50.0, max_level=4)
+    if batch > 1:
+        pipe.push(frames[0])
+        with pytest.raises(capi.SlamAmdError):      # its batch is neither complete nor flushed
+            pipe.result(0)
+        pipe.close()
+        pipe = FramePipeline(W, H, capi.orb_params(nfeatures=NF), 2048, depth=3, batch=batch,
+                             max_dist=300.0, area=50.0, max_level=4)
     got = pipe.run(frames, keep_results=True)
     pipe.close()
     po = oracle.params(nfeatures=NF)
