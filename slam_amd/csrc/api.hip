@@ -779,16 +779,18 @@ struct slam_amd_matcher {
     int sweep_kernel = 0;              // full sweep: 0 = matrix-core kernel (gates and ratio option included), 1 = VALU popcount kernel
     float ratio = 0.f;                 // options beyond the reference, both off by default
     int histo_length = 0;
+    DevBuf ticket;                     // [kFinalTicketProblems] counters of the finalize kernel, zero between calls
     DevBuf h_d1, h_k1, h_d2, h_k2, h_ids, h_xy, h_out, h_n, h_aux;  // host-call staging
 };
 
 // Scratch of slam_amd_frame_match_noalloc_async: running keys of up to kStaticRows queries, then
-// the (best, second) planes of the ratio option.  One copy per GPU, held until the process ends;
+// the (best, second) planes of the ratio option, then a ticket counter.  One copy per GPU, held until the process ends;
 // host code reaches it only through the address hipGetSymbolAddress returns for the current device.
 constexpr size_t kStaticRows = SLAM_AMD_NOALLOC_MAX_QUERIES;
 constexpr size_t kStaticBestBytes = kStaticRows * sizeof(unsigned);
 constexpr size_t kStaticPartBytes = kStaticRows * kMaxSecondSplits * sizeof(uint2);
-static __device__ __align__(256) unsigned char scratch[kStaticBestBytes + kStaticPartBytes];
+constexpr size_t kStaticTicketBytes = 256;      // the ticket counter of the workgroups that turn keys into records (zero between calls)
+static __device__ __align__(256) unsigned char scratch[kStaticBestBytes + kStaticPartBytes + kStaticTicketBytes];
 
 extern "C" int slam_amd_matcher_create(int device, slam_amd_matcher** out) {
     if (!out) SA_FAIL(SLAM_AMD_ERR_ARG, "out is null");
@@ -812,6 +814,14 @@ extern "C" int slam_amd_matcher_create(int device, slam_amd_matcher** out) {
         return hip_fail(e != hipSuccess ? e : hipErrorInvalidSymbol, "hipGetSymbolAddress(scratch)", __FILE__, __LINE__);
     }
     m->static_scratch = static_cast<unsigned char*>(sp);
+    // ticket counters of the finalize kernel's workgroups, one per problem of a call: zero here and after every call
+    rc = m->ticket.reserve(kFinalTicketProblems * sizeof(unsigned));
+    if (rc == SLAM_AMD_OK && (hipMemset(m->ticket.p, 0, m->ticket.cap) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) {
+        (void)hipGetLastError();
+        set_error("fill of the matcher's ticket counters failed");
+        rc = SLAM_AMD_ERR_HIP;
+    }
+    if (rc) { slam_amd_matcher_destroy(m); return rc; }
     *out = m;
     return SLAM_AMD_OK;
 }
@@ -820,7 +830,7 @@ extern "C" int slam_amd_matcher_destroy(slam_amd_matcher* m) {
     if (!m) return SLAM_AMD_OK;
     (void)hipSetDevice(m->device);
     if (m->stream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); }
-    for (DevBuf* b : {&m->best, &m->part, &m->sorted, &m->h_d1, &m->h_k1, &m->h_d2, &m->h_k2, &m->h_ids, &m->h_xy, &m->h_out,
+    for (DevBuf* b : {&m->best, &m->part, &m->sorted, &m->ticket, &m->h_d1, &m->h_k1, &m->h_d2, &m->h_k2, &m->h_ids, &m->h_xy, &m->h_out,
                       &m->h_n, &m->h_aux})
         b->release();
     delete m;
@@ -1041,6 +1051,8 @@ static int match_common(slam_amd_matcher* m, int batch,
     f.ratio = m->ratio; f.histo_length = m->histo_length; f.qkp = k1; f.tkp = k2; f.cap2 = cap2;
     f.chain = chain ? 1 : 0; f.d_n2 = d_n2;
     f.reset = self_clean ? best_p : nullptr;
+    f.ticket = no_alloc ? reinterpret_cast<unsigned*>(m->static_scratch + kStaticBestBytes + kStaticPartBytes) : m->ticket.as<unsigned>();
+    f.nq_bound = nq;
     if (capturing) m->baked = true;
     ProfScope ps(kStageFinalize, st);
     rc = launch_finalize(f, batch, st);

@@ -201,7 +201,11 @@ struct FinalizeArgs {
     int chain;                // as in MatchArgs
     const int32_t* d_n2;      // chained batches: the counts of set 2 are the query counts of the next problem
     unsigned* reset;          // if set (= best): every key read is put back to "no match", so the next call needs no fill
+    unsigned* ticket;         // [batch] zeros, or null: with it a problem of many queries is spread over workgroups
+    int nq_bound;             // host bound on a problem's queries (decides how many workgroups are launched)
+    int multi;                // set by the launcher: grid = (workgroups of a problem, problems) instead of (problems)
 };
+constexpr int kFinalTicketProblems = 16384;   // problems per call the ticket array serves
 
 struct ProjectArgs {
     double Rt[12];

@@ -203,12 +203,14 @@ __device__ __forceinline__ int rotation_bin(float angle_q, float angle_t, int le
 
 constexpr int kFinalRows = 8;                      // rows of 64 queries per wave and chunk
 constexpr int kFinalChunk = 16 * kFinalRows * 64;  // queries per chunk of the 16 waves
+constexpr int kFinalRowsMulti = 2;                 // the same where a problem is spread over workgroups, one chunk each
+constexpr int kFinalChunkMulti = 16 * kFinalRowsMulti * 64;
 
 template <bool EX>
 __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) {
     __shared__ int s_wave[16];
     __shared__ int s_hist[EX ? 64 : 1];
-    const int prob = blockIdx.x;
+    const int prob = a.multi ? blockIdx.y : blockIdx.x;
     const QuerySide qs = query_side(a.chain, prob, nullptr, a.qkp, a.d_n1, a.cap1, nullptr, a.tkp, a.d_n2, a.cap2);
     int n1 = a.n1;
     if (qs.count) n1 = min(n1, *qs.count);
@@ -270,6 +272,72 @@ __global__ __launch_bounds__(1024) void finalize_matches_kernel(FinalizeArgs a) 
         }
         return key;
     };
+    // A problem spread over gridDim.x workgroups (plain keys only): workgroup c owns queries
+    // [c, c + 1) * kFinalChunkMulti.  Its first output slot is the number of matches kept before its
+    // chunk, which it counts for itself from the keys (a few coalesced loads per thread, from L2) --
+    // no workgroup waits for another.  Nobody may put keys back while others still count them: the
+    // workgroups draw a ticket when they are done reading, and the last one puts the problem's keys
+    // back to "no match" and the ticket counter to zero.
+    if (!EX && a.multi) {
+        const int c = blockIdx.x;
+        const int chunks = max(1, (nq + kFinalChunkMulti - 1) / kFinalChunkMulti);
+        if (c >= chunks) return;                 // (uniform; the host's bound on the queries was not tight)
+        // (per-lane sums and one reduction at the end: nothing between the loads of different trips, so they overlap)
+        int before = 0;
+#pragma unroll 8
+        for (int q = threadIdx.x; q < c * kFinalChunkMulti; q += 1024) before += accepted(q) != kNoMatch;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) before += __shfl_xor(before, o, 64);
+        unsigned key[kFinalRowsMulti];
+        unsigned long long mask[kFinalRowsMulti];
+        int wcount = 0;
+        const int base = c * kFinalChunkMulti;
+#pragma unroll
+        for (int k = 0; k < kFinalRowsMulti; k++) {
+            const int q = base + (wave * kFinalRowsMulti + k) * 64 + lane;
+            key[k] = q < nq ? accepted(q) : kNoMatch;
+            mask[k] = __ballot(key[k] != kNoMatch);
+            wcount += __popcll(mask[k]);
+        }
+        __shared__ int s_pre[16];
+        if (lane == 0) { s_wave[wave] = wcount; s_pre[wave] = before; }
+        __syncthreads();
+        int pos = 0, total = 0;
+        for (int w = 0; w < 16; w++) {
+            const int v = s_wave[w];
+            pos += s_pre[w] + (w < wave ? v : 0);
+            total += s_pre[w] + v;
+        }
+        const unsigned long long below_ = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int k = 0; k < kFinalRowsMulti; k++) {
+            if (key[k] != kNoMatch) {
+                const int q = base + (wave * kFinalRowsMulti + k) * 64 + lane;
+                slam_amd_dmatch r;
+                r.queryIdx = a.ids ? a.ids[q] : q;
+                r.trainIdx = (int)(key[k] & ((1u << kIdxBits) - 1));
+                r.imgIdx = 0;
+                r.distance = (float)(key[k] >> kIdxBits);
+                out[pos + __popcll(mask[k] & below_)] = r;
+            }
+            pos += __popcll(mask[k]);
+        }
+        if (c == chunks - 1 && threadIdx.x == 0) a.n_out[prob] = total;
+        __shared__ int s_last;
+        __syncthreads();                          // every key this workgroup reads has been read
+        if (threadIdx.x == 0) {
+            __threadfence();
+            s_last = atomicAdd(&a.ticket[prob], 1u) == (unsigned)(chunks - 1);
+        }
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            if (a.reset)
+                for (int q = threadIdx.x; q < nq; q += 1024) a.reset[(size_t)prob * a.cap1 + q] = kNoMatch;
+            if (threadIdx.x == 0) a.ticket[prob] = 0u;
+        }
+        return;
+    }
     // Chunks of kFinalChunk queries, kFinalRows rows of 64 consecutive queries per wave:
     // keys are fetched once with coalesced loads and stay in registers; a ballot per
     // row gives the counts, one pass over the 16 wave totals gives the wave's first
@@ -487,8 +555,14 @@ int launch_match_pairs(MatchArgs a, int n_pairs, hipStream_t st) {
 
 int launch_finalize(const FinalizeArgs& a, int batch, hipStream_t st) {
     const bool ex = a.part != nullptr || a.histo_length > 0;
+    // plain keys, many queries: one workgroup per kFinalChunkMulti queries (blockIdx.y = problem)
+    const int chunks = (!ex && a.ticket && batch <= kFinalTicketProblems) ? div_up(std::max(a.nq_bound, 1), kFinalChunkMulti) : 1;
     if (ex) hipLaunchKernelGGL(finalize_matches_kernel<true>, dim3(batch), dim3(1024), 0, st, a);
-    else hipLaunchKernelGGL(finalize_matches_kernel<false>, dim3(batch), dim3(1024), 0, st, a);
+    else if (chunks > 2 && batch <= 65535) {
+        FinalizeArgs b = a;
+        b.multi = 1;
+        hipLaunchKernelGGL(finalize_matches_kernel<false>, dim3(chunks, batch), dim3(1024), 0, st, b);
+    } else hipLaunchKernelGGL(finalize_matches_kernel<false>, dim3(batch), dim3(1024), 0, st, a);
     SA_HIP(hipGetLastError());
     return SLAM_AMD_OK;
 }
