@@ -23,6 +23,9 @@
 #ifndef SA_FAST_EXP
 #define SA_FAST_EXP 0     // 1: fast_nms prints the clock at its phase boundaries for a few workgroups (timing experiments)
 #endif
+#ifndef SA_FAST_SKIP
+#define SA_FAST_SKIP 0    // timing experiments only (results are wrong): 1 no blur store, 2 no blur at all, 4 no ring test / score /
+#endif                    // suppression (list 1 taken as empty), 8 no compass test either, 16 tile not loaded from memory
 #if SA_FAST_EXP
 #define SA_STAMP_DECL unsigned long long stamp_[16] = {}
 #define SA_STAMP(i) stamp_[i] = __builtin_amdgcn_s_memtime()
@@ -63,20 +66,22 @@ namespace sa {
 
 // ---------------------------------------------------------------------------
 // FAST-9/16 + NMS + blur.  A workgroup owns a 64 x 32 tile of one level of one
-// frame.  The image tile with a 4-pixel halo is staged in LDS twice (reflect-101
-// outside the image): as bytes, for the gathers of the sparse phases, and split
-// into even / odd columns with one pixel per 16-bit field, so that the dense
-// phases handle two pixels per 32-bit add / sub / and / or (the instructions that
-// issue at full rate on this chip; packed 16-bit and three-operand ones take twice
-// as long).  Then
-//   phase 1  every position of the tile plus a 1-pixel halo: compass test (a
-//            9-arc always holds one pixel of every opposite pair); the survivors
-//            are compacted into an LDS list, each with the polarity it can have
-//   phase 2  full 16-pixel ring for the listed positions, one polarity (brighter
-//            arcs are darker arcs of the complemented pixels); corners are
-//            compacted into a second list
-//   phase 3  corner score for the listed corners, one polarity; meanwhile the
-//            vertical pass of the 7x7 blur runs on the split tile
+// frame.  The image tile with a 4-pixel halo is staged in LDS three times (reflect-101
+// outside the image): as bytes, for the gathers of the sparse phases; with every byte
+// shifted right by two (six bits per pixel), for the compass test, which handles four
+// pixels per 32-bit add / sub / and / or; and split into even / odd columns with one
+// pixel per 16-bit field, for the blur, which handles two pixels per 32-bit operation
+// (32-bit add / sub / and / or issue at full rate on this chip; packed 16-bit and
+// three-operand instructions take twice as long).  Then
+//   phase 1  every position of the tile plus a 1-pixel halo: compass test (a 9-arc
+//            always holds one pixel of every opposite pair) on the 6-bit pixels with
+//            the threshold rounded so that no pixel the exact test passes is lost;
+//            one LDS list entry per passing (pixel, polarity)
+//   phase 2  full 16-pixel ring on the exact bytes for the listed positions, one
+//            polarity each (brighter arcs are darker arcs of the complemented
+//            pixels): the corner score, which also says whether the position is a
+//            corner; corners are compacted into a second list
+//   phase 3  the vertical pass of the 7x7 blur on the split tile
 //   phase 4  3x3 strict-maximum suppression + border filter over the corner list
 //            -> survivor list and 256-bin score histogram; horizontal pass of
 //            the blur -> blurred level
@@ -95,6 +100,8 @@ constexpr int kScN = kScW * kScRows;                  // 2244 positions
 constexpr int kScBytes = ((kScRows * kScPitch + 15) / 16) * 16;
 constexpr int kListBytes = ((kScN * 2 + 15) / 16) * 16;
 constexpr int kVPitch = 2 * kImgDw;                   // dwords per row of the vertical-pass result
+constexpr int kQPitch = kImgDw + 1;                   // 6-bit tile: a spare dword before the 18 of a row (read, never used, by the
+                                                      // first column group's left neighbour; the last one's right neighbour is the next row's)
 
 __device__ __forceinline__ int div_up_dev(int a, int b) { return (a + b - 1) / b; }
 
@@ -165,9 +172,15 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     // list 1 (phases 1-2) and the vertical-pass result of the blur (phases 3-4) share one region
     __shared__ __align__(16) uint8_t s_scratch[kFastTileH * kVPitch * 4];
     __shared__ __align__(16) uint16_t s_list2[kListBytes / 2];
-    __shared__ unsigned s_n[3];   // lengths of list 1, list 2 and the survivor list
+    // lengths of list 1, list 2 and the survivor list; [3]: length of list 1 when it is rebuilt with one entry
+    // per pixel; [4]: set when the entries per (pixel, polarity) did not fit
+    __shared__ unsigned s_n[5];
     __shared__ unsigned s_cellbest[(kFastTileW / 8) * (kFastTileH / 8)];   // grid cells of >= 8 x 8 pixels
     uint16_t* s_list1 = reinterpret_cast<uint16_t*>(s_scratch);
+    constexpr unsigned kList1Cap = sizeof(s_scratch) / 2;
+    // the 6-bit tile of phase 1 lies where list 2 is built from phase 2 on
+    uint32_t* s_q = reinterpret_cast<uint32_t*>(s_list2);
+    static_assert((kImgRows * kQPitch + 1) * 4 <= kListBytes, "the 6-bit tile must fit the region of list 2");
     unsigned* s_v = reinterpret_cast<unsigned*>(s_scratch);   // [32][18] {even, odd} 16-bit column sums
     // this tile's survivors, lx | ly << 6 | score << 16, over the split tile (dead once the vertical blur pass is done)
     uint32_t* s_surv = reinterpret_cast<uint32_t*>(s_eo);
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     const int tid = threadIdx.x;
     SA_STAMP_DECL;
     SA_STAMP(0);
-    if (tid < 3) s_n[tid] = 0;
+    if (tid < 5) s_n[tid] = 0;
     if (tid < (kFastTileW / 8) * (kFastTileH / 8)) s_cellbest[tid] = 0;
     if (tid < kScBytes / 16) reinterpret_cast<uint4*>(s_sc)[tid] = make_uint4(0u, 0u, 0u, 0u);
     if (tid <= kImgRows) s_eo[tid * kEoPitch] = make_uint2(0u, 0u);
@@ -232,7 +245,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         // workgroup-uniform cases: a tile whose halo lies inside the level needs no reflection at all
         const bool inside = aligned && x0 >= kImgHalo && x0 + kFastTileW + kImgHalo <= w && y0 >= kImgHalo &&
                             y0 + kFastTileH + kImgHalo <= h;
-        if (inside) {
+        if (SA_FAST_SKIP & 16) {
+            for (int it = 0; it < 3; it++) v[it] = 0x40404040u + (unsigned)(tid & 3) * 0x01010101u;
+        } else if (inside) {
             const uint8_t* p0 = img + (size_t)(y0 - kImgHalo + rr) * pitch + gx;
 #pragma unroll
             for (int it = 0; it < 3; it++)
@@ -265,6 +280,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             if (r < kImgRows) {
                 *reinterpret_cast<uint32_t*>(s_img + r * P + 4 * cg) = v[it];
                 s_eo[r * kEoPitch + 1 + cg] = make_uint2(v[it] & 0x00ff00ffu, (v[it] >> 8) & 0x00ff00ffu);
+                s_q[r * kQPitch + 1 + cg] = (v[it] >> 2) & 0x3f3f3f3fu;
             }
         }
     }
@@ -274,20 +290,23 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     const int t = a.g.fast_threshold;
     const int edge = a.g.edge;
     const bool level_ok = (w > 2 * edge) && (h > 2 * edge);
-    // ---- phase 1: compass test, two pixels per 32-bit operation ----
+    // ---- phase 1: compass test, four pixels per 32-bit operation ----
     // Item (row r of the scored region, column group cg) covers staged columns 4cg .. 4cg+3 of
     // staged row r + 3.  With d = centre - compass pixel for the four compass points: an arc of 9
     // of the 16 ring pixels holds at least one pixel of every opposite pair, so a darker arc needs
     // (d0 > t or d8 > t) and (d4 > t or d12 > t), a brighter one the same with d < -t.
-    // Fields are 16 bits wide and hold values below 1024, so sums and differences of fields never
-    // carry into the neighbouring field: centre + 512 - (t + 1) - x has bit 9 set exactly when
-    // centre - x > t, and x + 512 - (t + 1) - centre when x - centre > t.
+    // The test runs on pixels shifted right by two, c = 4 c' + (0..3): c - x > t implies
+    // 4 (c' - x') + 3 >= t + 1, i.e. c' - x' >= k = (t + 1) / 4 rounded down -- every pixel the exact
+    // test passes passes this one (5 % more pass it; the ring test of phase 2 is exact).  A byte holds
+    // c' - x' + 128 - k, which stays within [65 - k, 191 - k]: no carry or borrow between the bytes of
+    // a word, and bit 7 says c' - x' >= k.
     // Only positions that can matter are tested: a keypoint lies at least `edge` pixels from
     // the level border and its 3x3 suppression looks one pixel further, so scores outside
     // [edge - 1, size - edge] are never read (edge >= 31 > 3, the FAST margin).
+    unsigned Yp = 0;   // flags of the thread's three items: pixel j of item `it`: bit 8 j + 2 it brighter, + 1 darker
+    const unsigned entry0 = ((unsigned)((rr + 3) * P + 4 * cg) >> 2) << 5;   // the thread's first item: staged offset / 4, above the bit number
     {
-        // valid pixels of this thread's column group, in the layout of the flag word: pixel 0, 1 at
-        // bits 0, 1 (darker) and 2, 3 (brighter), pixels 2, 3 at bits 16 .. 19
+        // valid pixels of this thread's column group: bits 7 and 6 of the pixel's byte
         unsigned cmask = 0;
         if (in_grid && level_ok) {
             // valid staged columns [clo, chi): the scored region, cut to image columns [edge - 1, w - edge]
@@ -295,12 +314,12 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             const unsigned span = (unsigned)max(chi - clo, 0);
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if ((unsigned)(4 * cg + j - clo) < span) cmask |= 5u << ((j & 1) + 16 * (j >> 1));
+                if ((unsigned)(4 * cg + j - clo) < span) cmask |= 0xc0u << (8 * j);
         }
-        // held in a vector register: an add with a scalar-register operand issues at half rate
-        unsigned KB = 0x02000200u - (unsigned)(t + 1) * 0x00010001u;
+        // held in vector registers: an operation with a scalar-register operand issues at half rate
+        unsigned KB = 0x80808080u - (unsigned)((t + 1) >> 2) * 0x01010101u, M7 = 0x80808080u;
         asm volatile("v_mov_b32 %0, %0" : "+v"(KB));
-        unsigned Y = 0;   // flags of the thread's three items: item `it` shifted left by 4 it
+        asm volatile("v_mov_b32 %0, %0" : "+v"(M7));
 #pragma unroll
         for (int it = 0; it < 3; it++) {
             const int r = rr + 14 * it;
@@ -308,31 +327,26 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             const bool row_ok = gy >= edge - 1 && gy < h - edge + 1;
             // (rows that cannot hold a keypoint or a neighbour of one are skipped: in the tiles along the upper
             // and lower border whole waves fall out; the reads stay inside the tile either way)
-            if (r < kScRows && row_ok && cmask != 0u) {     // (cmask is 0 where the level is too small for any keypoint)
-                const uint2* rowc = s_eo + (r + 3) * kEoPitch + 1 + cg;
-                const uint2 W0 = rowc[-1], C = rowc[0], W2 = rowc[1];
-                const uint2 U = s_eo[r * kEoPitch + 1 + cg], D = s_eo[(r + 6) * kEoPitch + 1 + cg];
-                // even centres (pixels 0, 2): left = odd fields of the group before, right = pixels 3, 5
-                const unsigned RE = __builtin_amdgcn_alignbit(W2.y, C.y, 16);
-                // odd centres (pixels 1, 3): left = pixels -2, 0, right = even fields of the group after
-                const unsigned LO = __builtin_amdgcn_alignbit(C.x, W0.x, 16);
-                const unsigned klo_e = C.x + KB, khi_e = KB - C.x;
-                const unsigned klo_o = C.y + KB, khi_o = KB - C.y;
-                const unsigned dark_e = ((klo_e - U.x) | (klo_e - D.x)) & ((klo_e - W0.y) | (klo_e - RE));
-                const unsigned brig_e = ((U.x + khi_e) | (D.x + khi_e)) & ((W0.y + khi_e) | (RE + khi_e));
-                const unsigned dark_o = ((klo_o - U.y) | (klo_o - D.y)) & ((klo_o - LO) | (klo_o - W2.x));
-                const unsigned brig_o = ((U.y + khi_o) | (D.y + khi_o)) & ((LO + khi_o) | (W2.x + khi_o));
-                // bit 9 / 25 of each word -> bits 0 .. 3 / 16 .. 19, shifted left by 4 it
-                const unsigned y = (shift_right(dark_e, 9 - 4 * it) & (0x00010001u << (4 * it))) |
-                                   (shift_right(dark_o, 8 - 4 * it) & (0x00020002u << (4 * it))) |
-                                   (shift_right(brig_e, 7 - 4 * it) & (0x00040004u << (4 * it))) |
-                                   (shift_right(brig_o, 6 - 4 * it) & (0x00080008u << (4 * it)));
-                Y |= y & (cmask << (4 * it));
+            if (!(SA_FAST_SKIP & 8) && r < kScRows && row_ok && cmask != 0u) {     // (cmask is 0 where the level is too small for any keypoint)
+                const uint32_t* qc = s_q + (r + 3) * kQPitch + 1 + cg;
+                const unsigned W0 = qc[-1], C = qc[0], W2 = qc[1];
+                const unsigned U = s_q[r * kQPitch + 1 + cg], D = s_q[(r + 6) * kQPitch + 1 + cg];
+                const unsigned L = __builtin_amdgcn_alignbyte(C, W0, 1);     // columns - 3
+                const unsigned R = __builtin_amdgcn_alignbyte(W2, C, 3);     // columns + 3
+                const unsigned lo = C + KB, hi = KB - C;
+                const unsigned dark = ((lo - U) | (lo - D)) & ((lo - L) | (lo - R));
+                const unsigned brig = ((U + hi) | (D + hi)) & ((L + hi) | (R + hi));
+                const unsigned y = ((dark & M7) | ((brig & M7) >> 1)) & cmask;
+                Yp |= y >> (6 - 2 * it);
             }
         }
-        // one list entry per passing pixel: staged offset | darker << 12 | brighter << 14
-        unsigned E = (Y | (Y >> 2)) & 0x03330333u;
-        const int cnt = __builtin_popcount(E);
+        // One list entry per passing (pixel, polarity), so that the ring test handles one polarity per entry:
+        // (code0 / 4) << 5 | bit number in Yp (odd: darker).  The entry is taken apart by the phase that reads it,
+        // where every lane has one, not in the loop below, which runs as long as the wave's busiest lane needs.
+        // The list holds kList1Cap entries, more than any image but a contrived one produces; a wave whose
+        // entries do not fit raises s_n[4] instead of writing them, and the list is then rebuilt below with one
+        // entry per pixel (both flags), which always fits.
+        const int cnt = __builtin_popcount(Yp);
         const int incl = wave_incl_scan(cnt);
         const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total) {
@@ -341,15 +355,16 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             unsigned base = 0;
             if ((tid & 63) == 0) base = atomicAdd(&s_n[0], (unsigned)total);
             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            unsigned pos = base + (unsigned)(incl - cnt);
-            const unsigned code0 = (unsigned)((rr + 3) * P + 4 * cg);
-            while (E) {
-                const unsigned i = (unsigned)__builtin_ctz(E);
-                E &= E - 1;
-                // bit i: item (i & 15) >> 2, pixel 2 (i >> 4) + (i & 1)
-                const unsigned px = ((i >> 3) & 2u) | (i & 1u);
-                const unsigned code = code0 + (i & 12u) * (unsigned)(14 * P / 4) + px;
-                s_list1[pos++] = (uint16_t)(code | (((Y >> i) & 5u) << 12));
+            if (base + (unsigned)total <= kList1Cap) {
+                uint16_t* dst = s_list1 + base + (unsigned)(incl - cnt);
+                unsigned E = Yp;
+                while (E) {
+                    const unsigned i = (unsigned)__builtin_ctz(E);
+                    E &= E - 1;
+                    *dst++ = (uint16_t)(entry0 | i);
+                }
+            } else if ((tid & 63) == 0) {
+                s_n[4] = 1u;
             }
         }
     }
@@ -358,32 +373,72 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     SA_STAMP(4);
     // ---- phase 2: full ring, 9 contiguous darker (or, on complemented pixels, brighter) ----
     // The sign of (ring - (v - t)) says "darker"; alignbit shifts it into the mask.
-    const int n1 = (int)s_n[0];
+    const bool merged = s_n[4] != 0u;      // (workgroup-uniform)
+    if (merged) {
+        // the entries per (pixel, polarity) did not fit: one entry per pixel with both flags instead
+        unsigned E = (Yp | (Yp >> 1)) & 0x15151515u;
+        const int cnt = __builtin_popcount(E);
+        const int incl = wave_incl_scan(cnt);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        unsigned base = 0;
+        if ((tid & 63) == 0 && total) base = atomicAdd(&s_n[3], (unsigned)total);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        uint16_t* dst = s_list1 + base + (unsigned)(incl - cnt);
+        while (E) {
+            const unsigned i = (unsigned)__builtin_ctz(E);       // (even: the pixel's brighter flag)
+            E &= E - 1;
+            const unsigned f = (Yp >> i) & 3u;                   // bit 0 brighter, bit 1 darker
+            *dst++ = (uint16_t)(entry0 | i | (f >> 1) | ((f & 1u) << 15));
+        }
+        lds_barrier();
+    }
+    const int n1 = (SA_FAST_SKIP & 4) ? 0 : (int)(merged ? s_n[3] : s_n[0]);
+    // The score -- the largest threshold that still detects: the best arc's smallest difference, minus one -- says
+    // whether the pixel is a corner at all (best > t), so it is computed for every listed position while its ring
+    // is in registers: the gathers from the byte tile, not the arithmetic, bound this phase, and the corners need
+    // no second round of them.  A darker corner has no brighter arc and vice versa: one polarity per entry.
     for (int k0 = 0; k0 < n1; k0 += 256) {
         const int k = k0 + tid;
         bool corner = false;
         unsigned code = 0, pol = 0;
         if (k < n1) {
+            // entry: (staged offset of the thread's first item / 4) << 5 | bit number: pixel (bit >> 3) of item (bit >> 1) & 3,
+            // odd = darker; an entry of a rebuilt list has bit 0 = darker, bit 15 = brighter
             const unsigned e = s_list1[k];
-            code = e & 0xfffu;
+            code = ((e >> 3) & 0xffcu) + ((e >> 1) & 3u) * (unsigned)(14 * P) + ((e >> 3) & 3u);
             const uint8_t* p = s_img + code;
             constexpr int off[16] = SA_RING_OFFSETS(P);
-            unsigned ring[16];
+            int ring[16];
 #pragma unroll
             for (int j = 0; j < 16; j++) ring[j] = p[off[j]];
-            const unsigned v = p[0];
-            auto arc = [&](unsigned x) {
-                const unsigned lo = (v ^ x) - (unsigned)t;
-                unsigned mask = 0;
+            const int v = p[0];
+            auto arc_min = [&](int x) {       // x = 0: darker arcs, 0xff: brighter arcs (darker ones of the complemented pixels)
+                const int vx = v ^ x;
+                int d[16];
 #pragma unroll
-                for (int j = 0; j < 16; j++) mask = __builtin_amdgcn_alignbit(mask, (ring[j] ^ x) - lo, 31);
-                return has_run9(mask);
+                for (int j = 0; j < 16; j++) d[j] = vx - (ring[j] ^ x);
+                int lo3[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) lo3[j] = min(min(d[j], d[(j + 1) & 15]), d[(j + 2) & 15]);
+                int best = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) {
+                    const int lo9a = min(min(lo3[j], lo3[(j + 3) & 15]), lo3[(j + 6) & 15]);
+                    const int lo9b = min(min(lo3[j + 1], lo3[(j + 4) & 15]), lo3[(j + 7) & 15]);
+                    best = max(max(best, lo9a), lo9b);
+                }
+                return best;
             };
-            pol = (e >> 12) & 1u ? 0u : 1u;     // darker first where the compass test allows it
-            corner = arc(pol ? 0xffu : 0u);
-            if (!corner && (e & 0x5000u) == 0x5000u) {   // both polarities passed the compass test (rare)
+            pol = e & 1u ? 0u : 1u;     // darker where the entry says so
+            int best = arc_min(pol ? 0xff : 0);
+            if (merged && best <= t && (e & 0x8001u) == 0x8001u) {   // an entry of a rebuilt list with both flags
                 pol = 1u;
-                corner = arc(0xffu);
+                best = arc_min(0xff);
+            }
+            corner = best > t;
+            if (corner) {
+                const unsigned srow = (code * 1821u) >> 17;               // code / 72 for code < 40 * 72
+                s_sc[code - 6u * srow - (unsigned)(3 * kScPitch + 3)] = (uint8_t)(best - 1);   // (srow - 3) * 66 + (column - 3)
             }
         }
         list_append(corner, code | (pol << 12), s_list2, &s_n[1]);
@@ -391,36 +446,12 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     SA_STAMP(5);
     lds_barrier();
     SA_STAMP(6);
-    // ---- phase 3: score of the corners; vertical pass of the blur ----
-    // The score is the largest threshold that still detects: the best arc's smallest difference,
-    // minus one.  A darker corner has no brighter arc and vice versa, so one polarity suffices.
+    // ---- phase 3: vertical pass of the blur ----
     const int n2 = (int)s_n[1];
-    for (int k = tid; k < n2; k += 256) {
-        const unsigned e = s_list2[k];
-        const unsigned code = e & 0xfffu, x = (e >> 12) ? 0xffu : 0u;
-        const uint8_t* p = s_img + code;
-        constexpr int off[16] = SA_RING_OFFSETS(P);
-        const int v = (int)(p[0] ^ x);
-        int d[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) d[j] = v - (int)(p[off[j]] ^ x);
-        int lo3[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) lo3[j] = min(min(d[j], d[(j + 1) & 15]), d[(j + 2) & 15]);
-        int best = 0;
-#pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-            const int lo9a = min(min(lo3[j], lo3[(j + 3) & 15]), lo3[(j + 6) & 15]);
-            const int lo9b = min(min(lo3[j + 1], lo3[(j + 4) & 15]), lo3[(j + 7) & 15]);
-            best = max(max(best, lo9a), lo9b);
-        }
-        const unsigned srow = (code * 1821u) >> 17;               // code / 72 for code < 40 * 72
-        s_sc[code - 6u * srow - (unsigned)(3 * kScPitch + 3)] = (uint8_t)(best - 1);   // (srow - 3) * 66 + (column - 3)
-    }
     // Blur, vertical pass: 7 taps 18 34 49 55 49 34 18 (8.8 fixed point; each is rounded on its own and
     // they add up to 257, not 256) down the columns of the split tile; the result fits 16 bits per pixel.  Item = (column group and
     // parity, 4 output rows): 36 x 8 items.
-    for (int i = tid; i < 2 * kImgDw * (kFastTileH / 4); i += 256) {
+    for (int i = tid; !(SA_FAST_SKIP & 2) && i < 2 * kImgDw * (kFastTileH / 4); i += 256) {
         const int chunk = i / (2 * kImgDw), cp = i - chunk * (2 * kImgDw);
         const unsigned* src = reinterpret_cast<const unsigned*>(s_eo) + (4 * chunk + 1) * (2 * kEoPitch) + 2 + cp;
         unsigned pcol[10];
@@ -503,7 +534,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         uint8_t* blur = a.blur + (size_t)b * a.g.frame_bytes + L.off;
         const int og = tid & 15, lr = tid >> 4;
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
+        for (int half = 0; half < ((SA_FAST_SKIP & 2) ? 0 : 2); half++) {
             const int ly = lr + 16 * half;
             const int gy = y0 + ly;
             const uint2* vrow = reinterpret_cast<const uint2*>(s_v + ly * kVPitch) + og;   // group og + 1 is the item's own
@@ -518,7 +549,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             const unsigned o3 = dot2(B.x, 18u | 49u << 16, dot2(B.y, 34u | 55u << 16, dot2(C.x, 49u | 18u << 16, dot2(C.y, 34u, rnd))));
             // byte 2 of o0 .. o3 -> bytes 0 .. 3
             const unsigned lo = __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u), hi = __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);
-            if (gy < h) *reinterpret_cast<uint32_t*>(blur + blur_tiled_offset((unsigned)L.pitch, (unsigned)(x0 + 4 * og), (unsigned)gy)) = lo | hi;
+            if (gy < h && (!(SA_FAST_SKIP & 1) || (lo | hi) == 0x12345678u)) *reinterpret_cast<uint32_t*>(blur + blur_tiled_offset((unsigned)L.pitch, (unsigned)(x0 + 4 * og), (unsigned)gy)) = lo | hi;
         }
     }
     SA_STAMP(10);

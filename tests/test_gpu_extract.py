@@ -49,3 +49,25 @@ def test_extract_main_cpp_params_odd_size(oracle, capi):
 def test_extract_kitti_shape(oracle, capi):
     img = synth.scene(1241, 376, 3)
     _compare(oracle, capi, img, 4000)
+
+
+def test_extract_gradients_that_pass_the_compass_test_in_both_polarities(oracle, capi):
+    """A diagonal ramp 7 (x + y) mod 256: nearly every pixel has a darker neighbour three pixels up and left and a
+    brighter one three pixels down and right, so the pre-test passes it in both polarities and a tile's candidate
+    list does not hold an entry per (pixel, polarity) -- the kernel falls back to one entry per pixel.  Corners come
+    from the ramp's wrap lines and from squares pasted on top."""
+    y, x = np.mgrid[0:240, 0:320]
+    img = ((7 * (x + y)) % 256).astype(np.uint8)
+    rng = np.random.default_rng(11)
+    for _ in range(60):
+        cx, cy, r = rng.integers(40, 280), rng.integers(40, 200), rng.integers(3, 9)
+        img[cy - r:cy + r, cx - r:cx + r] = rng.integers(0, 256)
+    kp, d = _compare(oracle, capi, img, 1500)
+    assert len(kp) > 200
+
+
+def test_extract_noise(oracle, capi):
+    """Uniform noise: close to 2000 candidate entries in every 64 x 32 tile, corners everywhere."""
+    img = np.random.default_rng(5).integers(0, 256, size=(200, 264), dtype=np.uint8)
+    kp, d = _compare(oracle, capi, img, 3000)
+    assert len(kp) > 500
