@@ -152,6 +152,11 @@ __device__ __forceinline__ void list_append(bool flag, unsigned value, uint16_t*
     if (flag) list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)value;
 }
 
+// Minimum / maximum of the low 16 bits as signed numbers (the 16-bit two-operand forms issue at full rate; the 32-bit
+// and three-operand ones at half).  The upper half of the result is not used.
+__device__ __forceinline__ short min16(short a, short b) { return a < b ? a : b; }
+__device__ __forceinline__ short max16(short a, short b) { return a > b ? a : b; }
+
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(unsigned v) { return __builtin_bit_cast(us2, v); }
 __device__ __forceinline__ unsigned as_u32(us2 v) { return __builtin_bit_cast(unsigned, v); }
@@ -166,30 +171,44 @@ __device__ __forceinline__ unsigned dot2(unsigned a, unsigned b, unsigned c) {
                             -3 * P, -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3, 2 * P - 2, 3 * P - 1}
 
 __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
-    __shared__ __align__(16) uint8_t s_img[kImgRows * kImgPitch];
-    __shared__ __align__(16) uint2 s_eo[kImgRows * kEoPitch + 1];   // {even, odd} columns of every staged dword
-    __shared__ __align__(16) uint8_t s_sc[kScBytes];
-    // list 1 (phases 1-2) and the vertical-pass result of the blur (phases 3-4) share one region
-    __shared__ __align__(16) uint8_t s_scratch[kFastTileH * kVPitch * 4];
-    __shared__ __align__(16) uint16_t s_list2[kListBytes / 2];
-    // lengths of list 1, list 2 and the survivor list; [3]: length of list 1 when it is rebuilt with one entry
-    // per pixel; [4]: set when the entries per (pixel, polarity) did not fit
-    __shared__ unsigned s_n[5];
-    __shared__ unsigned s_cellbest[(kFastTileW / 8) * (kFastTileH / 8)];   // grid cells of >= 8 x 8 pixels
+    // One block of LDS carved by hand (separately declared arrays get padded and ordered by the compiler, and four
+    // bytes too many cost a workgroup per CU: 8 workgroups need 160 KB / 8 each; 7 are 4 % slower, 5 27 %).
+    //   s_img      byte tile                                  (dead after phase 2; then: grid cells, survivor list)
+    //   s_sc       score map
+    //   s_scratch  list 1 (phases 1-2), then the vertical-pass result of the blur (phases 3-4)
+    //   s_list2    the 6-bit tile (phase 1), then the corner lists, one segment per wave (phases 2-4)
+    //   s_eo       {even, odd} columns of every staged dword, one pixel per 16-bit field
+    //   s_n        [0] length of list 1, [2] of the survivor list, [3] of list 1 when it is rebuilt with one entry per
+    //              pixel, [4] set when the entries per (pixel, polarity) did not fit
+    constexpr int kWaves = 4;
+    constexpr int kSegEntries = ((kScN + 255) / 256) * 64;     // corners one wave can find: its 64 of every 256 entries
+    constexpr int kSegBytes = kSegEntries * 2;
+    constexpr int kOffImg = 0, kOffSc = kOffImg + kImgRows * kImgPitch, kOffScratch = kOffSc + kScBytes,
+                  kOffList2 = kOffScratch + kFastTileH * kVPitch * 4, kOffEo = kOffList2 + kWaves * kSegBytes,
+                  kOffN = kOffEo + (kImgRows * kEoPitch + 1) * 8, kLdsBytes = kOffN + 5 * 4;
+    static_assert(kLdsBytes <= 20480, "LDS of fast_nms");
+    static_assert(kOffSc % 16 == 0 && kOffScratch % 16 == 0 && kOffList2 % 16 == 0 && kOffEo % 8 == 0 && kOffN % 4 == 0, "LDS alignment");
+    __shared__ __align__(16) uint8_t s_mem[kLdsBytes];
+    uint8_t* const s_img = s_mem + kOffImg;
+    uint8_t* const s_sc = s_mem + kOffSc;
+    uint8_t* const s_scratch = s_mem + kOffScratch;
+    uint16_t* const s_list2 = reinterpret_cast<uint16_t*>(s_mem + kOffList2);
+    uint2* const s_eo = reinterpret_cast<uint2*>(s_mem + kOffEo);
+    unsigned* const s_n = reinterpret_cast<unsigned*>(s_mem + kOffN);
     uint16_t* s_list1 = reinterpret_cast<uint16_t*>(s_scratch);
-    constexpr unsigned kList1Cap = sizeof(s_scratch) / 2;
-    // the 6-bit tile of phase 1 lies where list 2 is built from phase 2 on
+    constexpr unsigned kList1Cap = kFastTileH * kVPitch * 4 / 2;
+    // the 6-bit tile of phase 1 lies where the corner lists are built from phase 2 on
     uint32_t* s_q = reinterpret_cast<uint32_t*>(s_list2);
-    static_assert((kImgRows * kQPitch + 1) * 4 <= kListBytes, "the 6-bit tile must fit the region of list 2");
+    static_assert((kImgRows * kQPitch + 1) * 4 <= kWaves * kSegBytes, "the 6-bit tile must fit the region of the corner lists");
     unsigned* s_v = reinterpret_cast<unsigned*>(s_scratch);   // [32][18] {even, odd} 16-bit column sums
-    // this tile's survivors, lx | ly << 6 | score << 16, over the split tile (dead once the vertical blur pass is done)
-    uint32_t* s_surv = reinterpret_cast<uint32_t*>(s_eo);
-    static_assert(kTileListCap * 4 <= (int)sizeof(s_eo), "survivor list must fit the split tile");
-    static_assert(kListBytes <= (int)sizeof(s_scratch), "list 1 must fit the scratch region");
+    // grid cells of >= 8 x 8 pixels (grid option) and this tile's survivors, lx | ly << 6 | score << 16, over the byte
+    // tile (dead once the ring test is done)
+    unsigned* const s_cellbest = reinterpret_cast<unsigned*>(s_img);
+    constexpr int kCells = (kFastTileW / 8) * (kFastTileH / 8);
+    uint32_t* s_surv = reinterpret_cast<uint32_t*>(s_img) + kCells;
+    static_assert((kTileListCap + kCells) * 4 <= kImgRows * kImgPitch, "survivor list and grid cells must fit the byte tile");
+    static_assert(kListBytes <= kFastTileH * kVPitch * 4, "list 1 must fit the scratch region");
     constexpr int P = kImgPitch;
-    // 8 workgroups per CU need 160 KB / 8 each; the kernel gains 4 % over 7 (and loses 27 % at 5)
-    static_assert(sizeof(s_img) + sizeof(s_eo) + sizeof(s_sc) + sizeof(s_scratch) + sizeof(s_list2) + sizeof(s_n) + sizeof(s_cellbest) <= 20480,
-                  "LDS of fast_nms");
 
     // Grid: x = tile slot of a frame (a multiple of 8 of them), y = frame.  Workgroups are dealt
     // round-robin over the 8 XCDs, each with its own L2, in x-fastest order, so XCD k sees the slots
@@ -231,7 +250,6 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     SA_STAMP_DECL;
     SA_STAMP(0);
     if (tid < 5) s_n[tid] = 0;
-    if (tid < (kFastTileW / 8) * (kFastTileH / 8)) s_cellbest[tid] = 0;
     if (tid < kScBytes / 16) reinterpret_cast<uint4*>(s_sc)[tid] = make_uint4(0u, 0u, 0u, 0u);
     if (tid <= kImgRows) s_eo[tid * kEoPitch] = make_uint2(0u, 0u);
     // Thread (column group cg, row rr) of an 18 x 14 arrangement: one dword column
@@ -395,8 +413,18 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     const int n1 = (SA_FAST_SKIP & 4) ? 0 : (int)(merged ? s_n[3] : s_n[0]);
     // The score -- the largest threshold that still detects: the best arc's smallest difference, minus one -- says
     // whether the pixel is a corner at all (best > t), so it is computed for every listed position while its ring
-    // is in registers: the gathers from the byte tile, not the arithmetic, bound this phase, and the corners need
-    // no second round of them.  A darker corner has no brighter arc and vice versa: one polarity per entry.
+    // is in registers: the corners need no second round of gathers.  A darker corner has no brighter arc and vice
+    // versa: one polarity per entry.  With e[j] = centre - ring pixel j a darker arc has all e > t; a brighter one
+    // all -e > t, tested as e ^ -1 = -e - 1 (one xor per pixel selects the polarity per lane) with the 1 put back at
+    // the end.  The 16 arcs of 9 pixels share their middles: arc k and arc k + 1 (k even) are pixels k + 1 .. k + 8
+    // plus pixel k or pixel k + 9, and those middles are built from 8 pair minima -- 56 two-operand minima and maxima
+    // in all, issued as 16-bit operations (differences fit 10 bits), which run at twice the rate of the 32-bit and
+    // three-operand forms.
+    // Corners go to a list per wave (the wave that found them also suppresses them): its length stays in a scalar
+    // register, and appending takes a ballot and a lane count, no atomic.
+    const int wave = tid >> 6;
+    uint16_t* const my_list2 = s_list2 + wave * kSegEntries;
+    int n2 = 0;       // corners in this wave's list (wave-uniform)
     for (int k0 = 0; k0 < n1; k0 += 256) {
         const int k = k0 + tid;
         bool corner = false;
@@ -408,32 +436,32 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             code = ((e >> 3) & 0xffcu) + ((e >> 1) & 3u) * (unsigned)(14 * P) + ((e >> 3) & 3u);
             const uint8_t* p = s_img + code;
             constexpr int off[16] = SA_RING_OFFSETS(P);
-            int ring[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) ring[j] = p[off[j]];
+            int ev[16];
             const int v = p[0];
-            auto arc_min = [&](int x) {       // x = 0: darker arcs, 0xff: brighter arcs (darker ones of the complemented pixels)
-                const int vx = v ^ x;
-                int d[16];
 #pragma unroll
-                for (int j = 0; j < 16; j++) d[j] = vx - (ring[j] ^ x);
-                int lo3[16];
+            for (int j = 0; j < 16; j++) ev[j] = v - (int)p[off[j]];
+            auto arc_best = [&](int m) {       // m = 0: darker arcs, -1: brighter arcs; returns the best arc's minimum (clamped at -1)
+                short d[16];
 #pragma unroll
-                for (int j = 0; j < 16; j++) lo3[j] = min(min(d[j], d[(j + 1) & 15]), d[(j + 2) & 15]);
-                int best = 0;
+                for (int j = 0; j < 16; j++) d[j] = (short)(ev[j] ^ m);
+                short pm[8], qm[8];
 #pragma unroll
-                for (int j = 0; j < 16; j += 2) {
-                    const int lo9a = min(min(lo3[j], lo3[(j + 3) & 15]), lo3[(j + 6) & 15]);
-                    const int lo9b = min(min(lo3[j + 1], lo3[(j + 4) & 15]), lo3[(j + 7) & 15]);
-                    best = max(max(best, lo9a), lo9b);
+                for (int i = 0; i < 8; i++) pm[i] = min16(d[2 * i + 1], d[(2 * i + 2) & 15]);
+#pragma unroll
+                for (int i = 0; i < 8; i++) qm[i] = min16(pm[i], pm[(i + 1) & 7]);
+                short best = -1;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const short core = min16(qm[i], qm[(i + 2) & 7]);        // pixels 2i + 1 .. 2i + 8
+                    best = max16(best, max16(min16(core, d[2 * i]), min16(core, d[(2 * i + 9) & 15])));
                 }
-                return best;
+                return (int)best - m;
             };
             pol = e & 1u ? 0u : 1u;     // darker where the entry says so
-            int best = arc_min(pol ? 0xff : 0);
+            int best = arc_best(pol ? -1 : 0);
             if (merged && best <= t && (e & 0x8001u) == 0x8001u) {   // an entry of a rebuilt list with both flags
                 pol = 1u;
-                best = arc_min(0xff);
+                best = arc_best(-1);
             }
             corner = best > t;
             if (corner) {
@@ -441,13 +469,15 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
                 s_sc[code - 6u * srow - (unsigned)(3 * kScPitch + 3)] = (uint8_t)(best - 1);   // (srow - 3) * 66 + (column - 3)
             }
         }
-        list_append(corner, code | (pol << 12), s_list2, &s_n[1]);
+        const unsigned long long cm = __ballot(corner);
+        if (corner) my_list2[n2 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u))] = (uint16_t)(code | (pol << 12));
+        n2 += __builtin_popcountll(cm);
     }
     SA_STAMP(5);
     lds_barrier();
     SA_STAMP(6);
     // ---- phase 3: vertical pass of the blur ----
-    const int n2 = (int)s_n[1];
+    if (a.grid_shift && tid < kCells) s_cellbest[tid] = 0;     // (the byte tile is dead from here on)
     // Blur, vertical pass: 7 taps 18 34 49 55 49 34 18 (8.8 fixed point; each is rounded on its own and
     // they add up to 257, not 256) down the columns of the split tile; the result fits 16 bits per pixel.  Item = (column group and
     // parity, 4 output rows): 36 x 8 items.
@@ -477,7 +507,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         // survivor of list entry k: lx | ly << 6 | score << 16, or 0
         auto survivor = [&](int k) -> unsigned {
             if (k >= n2) return 0u;
-            const unsigned code = s_list2[k] & 0xfffu;
+            const unsigned code = my_list2[k] & 0xfffu;
             const unsigned sr = (code * 1821u) >> 17;            // code / 72 for code < 40 * 72
             const int lx = (int)(code - sr * P) - kImgHalo, ly = (int)sr - kImgHalo;
             const int gx = x0 + lx, gy = y0 + ly;
@@ -502,14 +532,14 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             return (sv & 0xffff0000u) | (0xffffu - (unsigned)(ly * kFastTileW + lx));
         };
         if (sh) {
-            for (int k0 = 0; k0 < n2; k0 += 256) {
-                const unsigned sv = survivor(k0 + tid);
+            for (int k0 = 0; k0 < n2; k0 += 64) {
+                const unsigned sv = survivor(k0 + (tid & 63));
                 if (sv) { int cell; const unsigned key = cell_key(sv, cell); atomicMax(&s_cellbest[cell], key); }
             }
             lds_barrier();      // uniform: grid_shift is a kernel argument
         }
-        for (int k0 = 0; k0 < n2; k0 += 256) {
-            unsigned sv = survivor(k0 + tid);
+        for (int k0 = 0; k0 < n2; k0 += 64) {
+            unsigned sv = survivor(k0 + (tid & 63));
             if (sh && sv) { int cell; const unsigned key = cell_key(sv, cell); if (s_cellbest[cell] != key) sv = 0; }
             const unsigned long long m = __ballot(sv != 0);
             if (m) {
