@@ -1190,7 +1190,12 @@ __global__ __launch_bounds__(1024) void quadtree_select_kernel(SelectCompactArgs
 // ---------------------------------------------------------------------------
 constexpr int kURad = 15, kURows = 31;
 constexpr int kBRad = 18, kBRows = 37;
-constexpr int kPPitch = 64;        // LDS bytes per row of the blurred patch
+#ifndef SA_DESC_PITCH
+#define SA_DESC_PITCH 80
+#endif
+constexpr int kPPitch = SA_DESC_PITCH;   // LDS bytes per row of the blurred patch: a multiple of 16 (16-byte stores) whose rows start on
+                                         // 8 different bank offsets (20 r mod 32); with 64 bytes the 37 rows fall on 2 and the samples
+                                         // of a wave, which lie within 13 pixels of the centre, on half of the 32 banks
 constexpr int kBLoadRows = 48;     // rows fetched at most: from the tile row that holds the patch's first row (up to 7 rows above it)
 
 // rBRIEF sampling pattern as floats: x0, y0, x1, y1 of pair p at [4 * p].
@@ -1419,15 +1424,15 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
         // Rounding to the nearest integer, ties to even, as the low bits of x + 1.5 * 2^23; the sum's bit
-        // pattern is 0x4B400000 + the integer.  Row * 64 + column on the patterns themselves, the two
+        // pattern is 0x4B400000 + the integer.  Row * pitch + column on the patterns themselves, the two
         // offsets taken off at the end (together with the patch centre's place in s_patch).
         constexpr float kMagic = 12582912.0f;
         constexpr unsigned kMagicBits = 0x4B400000u;
-        constexpr unsigned kUnbias = (kMagicBits << 6) + kMagicBits - (unsigned)(kBRad * kPPitch + kBRad);
+        constexpr unsigned kUnbias = (kMagicBits & 0xffffffu) * (unsigned)kPPitch + kMagicBits - (unsigned)(kBRad * kPPitch + kBRad);
         const unsigned s_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_patch - kUnbias;
         auto sample_at = [&](float fx, float fy, unsigned origin) -> int {
             const unsigned bx = __builtin_bit_cast(unsigned, SA_FADD(fx, kMagic)), by = __builtin_bit_cast(unsigned, SA_FADD(fy, kMagic));
-            const unsigned at = (by << 6) + bx + origin;
+            const unsigned at = (unsigned)__umul24(by, (unsigned)kPPitch) + bx + origin;    // the row number is the low 24 bits of by
             return *(__attribute__((address_space(3))) const uint8_t*)(uintptr_t)at;
         };
         // kDescAhead patches are in flight ahead of the one being sampled
@@ -1437,14 +1442,14 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
 #pragma unroll
         for (int j = 0; j < kDescKps; j++) {
             *reinterpret_cast<u32x4*>(w0) = ahead[j % kDescAhead].v0;
-            *reinterpret_cast<u32x4*>(w0 + 1024) = ahead[j % kDescAhead].v1;
-            *reinterpret_cast<u32x4*>(w0 + 2048) = ahead[j % kDescAhead].v2;
+            *reinterpret_cast<u32x4*>(w0 + 16 * kPPitch) = ahead[j % kDescAhead].v1;
+            *reinterpret_cast<u32x4*>(w0 + 32 * kPPitch) = ahead[j % kDescAhead].v2;
             if (j + kDescAhead < kDescKps) ahead[j % kDescAhead] = load_b(min(j + kDescAhead, nk - 1));
             lds_order();
             // (copies in vector registers: an instruction with a scalar-register operand issues at half rate)
             float ca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cav), j));
             float sn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, snv), j));
-            unsigned origin = s_base + (unsigned)__builtin_amdgcn_readlane(bshift + (yshift << 6), j);
+            unsigned origin = s_base + (unsigned)__builtin_amdgcn_readlane(bshift + yshift * kPPitch, j);
             asm volatile("v_mov_b32 %0, %0" : "+v"(ca));
             asm volatile("v_mov_b32 %0, %0" : "+v"(sn));
             asm volatile("v_mov_b32 %0, %0" : "+v"(origin));
