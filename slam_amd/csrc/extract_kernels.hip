@@ -66,12 +66,10 @@ namespace sa {
 
 // ---------------------------------------------------------------------------
 // FAST-9/16 + NMS + blur.  A workgroup owns a 64 x 32 tile of one level of one
-// frame.  The image tile with a 4-pixel halo is staged in LDS three times (reflect-101
-// outside the image): as bytes, for the gathers of the sparse phases; with every byte
+// frame.  The image tile with a 4-pixel halo is staged in LDS twice (reflect-101
+// outside the image): as bytes, for the gathers of the sparse phases and the blur; and with every byte
 // shifted right by two (six bits per pixel), for the compass test, which handles four
-// pixels per 32-bit add / sub / and / or; and split into even / odd columns with one
-// pixel per 16-bit field, for the blur, which handles two pixels per 32-bit operation
-// (32-bit add / sub / and / or issue at full rate on this chip; packed 16-bit and
+// pixels per 32-bit add / sub / and / or (32-bit add / sub / and / or issue at full rate on this chip; packed 16-bit and
 // three-operand instructions take twice as long).  Then
 //   phase 1  every position of the tile plus a 1-pixel halo: compass test (a 9-arc
 //            always holds one pixel of every opposite pair) on the 6-bit pixels with
@@ -80,26 +78,25 @@ namespace sa {
 //   phase 2  full 16-pixel ring on the exact bytes for the listed positions, one
 //            polarity each (brighter arcs are darker arcs of the complemented
 //            pixels): the corner score, which also says whether the position is a
-//            corner; corners are compacted into a second list
-//   phase 3  the vertical pass of the 7x7 blur on the split tile
-//   phase 4  3x3 strict-maximum suppression + border filter over the corner list
-//            -> survivor list and 256-bin score histogram; horizontal pass of
-//            the blur -> blurred level
+//            corner; corners are compacted into a list per wave
+//   phase 3  the 7x7 blur of the tile as two banded matrix products on the matrix cores
+//            (see blur_tile) -> blurred level
+//   phase 4  3x3 strict-maximum suppression + border filter over the corner lists
+//            -> survivor list and 256-bin score histogram
 // The lists keep the expensive phases dense instead of divergent.
 // ---------------------------------------------------------------------------
 constexpr int kImgHalo = 4;
 constexpr int kImgDw = (kFastTileW + 2 * kImgHalo) / 4;   // 18 staged dwords per row
-constexpr int kImgPitch = 4 * kImgDw;                     // 72 bytes
+constexpr int kImgPitch = 80;                             // bytes per staged row: 72 of pixels, padded to a multiple of 16
+                                                          // (the blur reads rows in 16-byte pieces)
 constexpr int kImgRows = kFastTileH + 2 * kImgHalo;   // 40
-constexpr int kEoPitch = kImgDw + 1;                  // split tile: a zero entry before the 18 groups of a row (the one
-                                                      // after them is the next row's; one more closes the last row)
 constexpr int kScW = kFastTileW + 2;                  // 66 scored columns
 constexpr int kScRows = kFastTileH + 2;               // 34 scored rows
 constexpr int kScPitch = kScW;                        // score map: scored row r, column c at r * 66 + c (staged row r + 3, column c + 3)
 constexpr int kScN = kScW * kScRows;                  // 2244 positions
 constexpr int kScBytes = ((kScRows * kScPitch + 15) / 16) * 16;
 constexpr int kListBytes = ((kScN * 2 + 15) / 16) * 16;
-constexpr int kVPitch = 2 * kImgDw;                   // dwords per row of the vertical-pass result
+constexpr int kList1Bytes = 4608;                     // list 1: 2304 entries
 constexpr int kQPitch = kImgDw + 1;                   // 6-bit tile: a spare dword before the 18 of a row (read, never used, by the
                                                       // first column group's left neighbour; the last one's right neighbour is the next row's)
 
@@ -170,44 +167,124 @@ __device__ __forceinline__ unsigned dot2(unsigned a, unsigned b, unsigned c) {
 #define SA_RING_OFFSETS(P) {3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1, \
                             -3 * P, -3 * P - 1, -2 * P - 2, -P - 3, -3, P - 3, 2 * P - 2, 3 * P - 1}
 
+// Row of a byte offset in the staged tile: code / 80 for code < 40 * 80.
+__device__ __forceinline__ unsigned staged_row(unsigned code) { return (code * 3277u) >> 18; }
+static_assert(kImgPitch == 80, "staged_row divides by the pitch of the staged tile");
+
+// ---------------------------------------------------------------------------
+// 7x7 blur of a 64 x 32 tile on the matrix cores.  The blur is separable with 8-bit taps
+// 18 34 49 55 49 34 18 (8.8 fixed point; each is rounded on its own and they add up to 257, not 256), no rounding
+// between the passes and one at the end: out = min((sum + 2^15) >> 16, 255).  Each pass is a product with a banded
+// matrix of taps, exact in 32-bit integers, on v_mfma_i32_16x16x64_i8 (D = A B + C; lane l holds row l & 15 of A
+// and column l & 15 of B, 16 of the 64 k each: k group l >> 4, and D[4 (l >> 4) + i][l & 15] in register i).
+// Wave w takes the columns 16 w .. 16 w + 15 of the tile:
+//   horizontal  H[r][c] = sum_t tap[t] p[r][c - 3 + t] for the 38 rows the vertical pass needs, as three products
+//               of 16 rows: A = 16 bytes of a staged row per lane (pixels - 128: the product is signed), B[k][n] =
+//               tap[k - n - 1], C = 128 * 257, so that D = H, 16 bits.  A lane ends up with H of ONE column, rows
+//               16 m + 4 (l >> 4) + i in register i of product m.
+//   vertical    out[r][c] = sum_t tap[t] H[r + t][c] sums over the row index of H, which lies in the registers of a
+//               lane: the lane's H values are the A operand as they stand (k slot (l >> 4, j) = row 16 (j >> 2) +
+//               4 (l >> 4) + (j & 3), byte j & 3 of dword j >> 2: the four results of product j >> 2, packed), once
+//               their low bytes and once their high bytes (as signed bytes again), B[k][n] = tap[row of k - n] --
+//               the result has the image row on the lane and four neighbouring columns in the registers, which is
+//               how the blurred level is stored (a dword per lane).  sum = low + 256 high + the constants.
+// The k slots of the two operands only have to agree with each other, and both are built here.
+// ---------------------------------------------------------------------------
+struct BlurTaps { unsigned h[64][4], v[64][4]; };
+constexpr BlurTaps make_blur_taps() {
+    constexpr int tap[7] = {18, 34, 49, 55, 49, 34, 18};
+    BlurTaps t = {};
+    for (int l = 0; l < 64; l++) {
+        const int n = l & 15, kg = l >> 4;
+        for (int j = 0; j < 16; j++) {
+            const int th = 16 * kg + j - n - 1;                          // horizontal: k = 16 kg + j is staged column 16 w + k
+            const int tv = 16 * (j >> 2) + 4 * kg + (j & 3) - n;         // vertical, rows 0 .. 15 of the tile: row of the k slot - n
+            if (th >= 0 && th < 7) t.h[l][j >> 2] |= (unsigned)tap[th] << (8 * (j & 3));
+            if (tv >= 0 && tv < 7) t.v[l][j >> 2] |= (unsigned)tap[tv] << (8 * (j & 3));
+        }
+    }
+    return t;
+}
+__device__ const BlurTaps c_blur_taps = make_blur_taps();
+typedef int blur_v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void blur_tile(const uint8_t* s_img, int wave, int lane, uint8_t* blur_level, unsigned pitch, int x0, int y0, int h) {
+    const int n = lane & 15, kg = lane >> 4;
+    const uint4 th = *reinterpret_cast<const uint4*>(&c_blur_taps.h[lane][0]);
+    const uint2 tv = *reinterpret_cast<const uint2*>(&c_blur_taps.v[lane][0]);      // dwords 2 and 3 are zero
+    const blur_v4i bh = {(int)th.x, (int)th.y, (int)th.z, (int)th.w};
+    // ---- horizontal: H row hr = 16 m + n is staged row hr + 1 (rows past the staged tile are never used: clamped) ----
+    unsigned lo[3], hi[3];
+    const blur_v4i c_h = {128 * 257, 128 * 257, 128 * 257, 128 * 257};
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        const int row = min(16 * m + n + 1, kImgRows - 1);
+        uint4 p = make_uint4(0u, 0u, 0u, 0u);
+        if (kg < 2) p = *reinterpret_cast<const uint4*>(s_img + row * kImgPitch + 16 * wave + 16 * kg);   // (taps of k >= 23 are zero)
+        const blur_v4i av = {(int)(p.x ^ 0x80808080u), (int)(p.y ^ 0x80808080u), (int)(p.z ^ 0x80808080u), (int)(p.w ^ 0x80808080u)};
+        const blur_v4i d = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bh, c_h, 0, 0, 0);
+        // bytes 0 and 1 of the four results -> one dword each, as signed bytes
+        const unsigned p01 = __builtin_amdgcn_perm((unsigned)d.y, (unsigned)d.x, 0x05010400u);   // lo0 lo1 hi0 hi1
+        const unsigned p23 = __builtin_amdgcn_perm((unsigned)d.w, (unsigned)d.z, 0x05010400u);
+        lo[m] = __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ 0x80808080u;
+        hi[m] = __builtin_amdgcn_perm(p23, p01, 0x07060302u) ^ 0x80808080u;
+    }
+    // ---- vertical: rows r0 .. r0 + 15; H row of k slot (kg, j) is 16 (j >> 2) + 4 kg + (j & 3) ----
+    const blur_v4i a_lo = {(int)lo[0], (int)lo[1], (int)lo[2], 0}, a_hi = {(int)hi[0], (int)hi[1], (int)hi[2], 0};
+    constexpr int kC = 128 * 257 + 256 * 128 * 257 + 32768;      // the two offsets of 128 put back, and the rounding
+    const blur_v4i c_v = {kC, kC, kC, kC}, c_0 = {0, 0, 0, 0};
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const blur_v4i bv = half == 0 ? blur_v4i{(int)tv.x, (int)tv.y, 0, 0} : blur_v4i{0, (int)tv.x, (int)tv.y, 0};
+        const blur_v4i dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_lo, bv, c_v, 0, 0, 0);
+        const blur_v4i dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hi, bv, c_0, 0, 0, 0);
+        unsigned v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = ((unsigned)dh[i] << 8) + (unsigned)dl[i];       // < 2^24 + 2^17
+        // (v >> 16) of two results as 16-bit halves, clamped to 255; then the four low bytes
+        const us2 m255 = {255, 255};
+        const unsigned q01 = as_u32(__builtin_elementwise_min(as_us2(__builtin_amdgcn_perm(v[1], v[0], 0x07060302u)), m255));
+        const unsigned q23 = as_u32(__builtin_elementwise_min(as_us2(__builtin_amdgcn_perm(v[3], v[2], 0x07060302u)), m255));
+        const unsigned out = __builtin_amdgcn_perm(q23, q01, 0x06040200u);
+        const int gy = y0 + 16 * half + n;          // image row on the lane, columns x0 + 16 wave + 4 kg .. + 3 in `out`
+        if (gy < h && (!(SA_FAST_SKIP & 1) || out == 0x12345678u))
+            *reinterpret_cast<uint32_t*>(blur_level + blur_tiled_offset(pitch, (unsigned)(x0 + 16 * wave + 4 * kg), (unsigned)gy)) = out;
+    }
+}
+
 __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     // One block of LDS carved by hand (separately declared arrays get padded and ordered by the compiler, and four
     // bytes too many cost a workgroup per CU: 8 workgroups need 160 KB / 8 each; 7 are 4 % slower, 5 27 %).
-    //   s_img      byte tile                                  (dead after phase 2; then: grid cells, survivor list)
+    //   s_img      byte tile                                  (dead after phase 3; then: grid cells, survivor list)
     //   s_sc       score map
-    //   s_scratch  list 1 (phases 1-2), then the vertical-pass result of the blur (phases 3-4)
+    //   s_list1    list 1 (phases 1-2)
     //   s_list2    the 6-bit tile (phase 1), then the corner lists, one segment per wave (phases 2-4)
-    //   s_eo       {even, odd} columns of every staged dword, one pixel per 16-bit field
     //   s_n        [0] length of list 1, [2] of the survivor list, [3] of list 1 when it is rebuilt with one entry per
     //              pixel, [4] set when the entries per (pixel, polarity) did not fit
     constexpr int kWaves = 4;
     constexpr int kSegEntries = ((kScN + 255) / 256) * 64;     // corners one wave can find: its 64 of every 256 entries
     constexpr int kSegBytes = kSegEntries * 2;
-    constexpr int kOffImg = 0, kOffSc = kOffImg + kImgRows * kImgPitch, kOffScratch = kOffSc + kScBytes,
-                  kOffList2 = kOffScratch + kFastTileH * kVPitch * 4, kOffEo = kOffList2 + kWaves * kSegBytes,
-                  kOffN = kOffEo + (kImgRows * kEoPitch + 1) * 8, kLdsBytes = kOffN + 5 * 4;
+    constexpr int kOffImg = 0, kOffSc = kOffImg + kImgRows * kImgPitch, kOffList1 = kOffSc + kScBytes,
+                  kOffList2 = kOffList1 + kList1Bytes, kOffN = kOffList2 + kWaves * kSegBytes, kLdsBytes = kOffN + 5 * 4;
     static_assert(kLdsBytes <= 20480, "LDS of fast_nms");
-    static_assert(kOffSc % 16 == 0 && kOffScratch % 16 == 0 && kOffList2 % 16 == 0 && kOffEo % 8 == 0 && kOffN % 4 == 0, "LDS alignment");
+    static_assert(kOffSc % 16 == 0 && kOffList1 % 16 == 0 && kOffList2 % 16 == 0 && kOffN % 4 == 0, "LDS alignment");
     __shared__ __align__(16) uint8_t s_mem[kLdsBytes];
     uint8_t* const s_img = s_mem + kOffImg;
     uint8_t* const s_sc = s_mem + kOffSc;
-    uint8_t* const s_scratch = s_mem + kOffScratch;
+    uint16_t* const s_list1 = reinterpret_cast<uint16_t*>(s_mem + kOffList1);
     uint16_t* const s_list2 = reinterpret_cast<uint16_t*>(s_mem + kOffList2);
-    uint2* const s_eo = reinterpret_cast<uint2*>(s_mem + kOffEo);
     unsigned* const s_n = reinterpret_cast<unsigned*>(s_mem + kOffN);
-    uint16_t* s_list1 = reinterpret_cast<uint16_t*>(s_scratch);
-    constexpr unsigned kList1Cap = kFastTileH * kVPitch * 4 / 2;
+    constexpr unsigned kList1Cap = kList1Bytes / 2;
     // the 6-bit tile of phase 1 lies where the corner lists are built from phase 2 on
     uint32_t* s_q = reinterpret_cast<uint32_t*>(s_list2);
     static_assert((kImgRows * kQPitch + 1) * 4 <= kWaves * kSegBytes, "the 6-bit tile must fit the region of the corner lists");
-    unsigned* s_v = reinterpret_cast<unsigned*>(s_scratch);   // [32][18] {even, odd} 16-bit column sums
     // grid cells of >= 8 x 8 pixels (grid option) and this tile's survivors, lx | ly << 6 | score << 16, over the byte
-    // tile (dead once the ring test is done)
+    // tile (dead once the blur has read it)
     unsigned* const s_cellbest = reinterpret_cast<unsigned*>(s_img);
     constexpr int kCells = (kFastTileW / 8) * (kFastTileH / 8);
     uint32_t* s_surv = reinterpret_cast<uint32_t*>(s_img) + kCells;
     static_assert((kTileListCap + kCells) * 4 <= kImgRows * kImgPitch, "survivor list and grid cells must fit the byte tile");
-    static_assert(kListBytes <= kFastTileH * kVPitch * 4, "list 1 must fit the scratch region");
+    static_assert(kListBytes <= kList1Bytes, "list 1 must hold one entry per scored position");
     constexpr int P = kImgPitch;
 
     // Grid: x = tile slot of a frame (a multiple of 8 of them), y = frame.  Workgroups are dealt
@@ -251,7 +328,6 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     SA_STAMP(0);
     if (tid < 5) s_n[tid] = 0;
     if (tid < kScBytes / 16) reinterpret_cast<uint4*>(s_sc)[tid] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid <= kImgRows) s_eo[tid * kEoPitch] = make_uint2(0u, 0u);
     // Thread (column group cg, row rr) of an 18 x 14 arrangement: one dword column
     // of the staged tile, rows rr, rr + 14, rr + 28.  252 of the 256 threads take part.
     const int rr = tid / kImgDw, cg = tid - rr * kImgDw;
@@ -297,7 +373,6 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             const int r = rr + 14 * it;
             if (r < kImgRows) {
                 *reinterpret_cast<uint32_t*>(s_img + r * P + 4 * cg) = v[it];
-                s_eo[r * kEoPitch + 1 + cg] = make_uint2(v[it] & 0x00ff00ffu, (v[it] >> 8) & 0x00ff00ffu);
                 s_q[r * kQPitch + 1 + cg] = (v[it] >> 2) & 0x3f3f3f3fu;
             }
         }
@@ -465,8 +540,8 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             }
             corner = best > t;
             if (corner) {
-                const unsigned srow = (code * 1821u) >> 17;               // code / 72 for code < 40 * 72
-                s_sc[code - 6u * srow - (unsigned)(3 * kScPitch + 3)] = (uint8_t)(best - 1);   // (srow - 3) * 66 + (column - 3)
+                const unsigned srow = staged_row(code);
+                s_sc[code - (unsigned)(P - kScPitch) * srow - (unsigned)(3 * kScPitch + 3)] = (uint8_t)(best - 1);   // (srow - 3) * 66 + (column - 3)
             }
         }
         const unsigned long long cm = __ballot(corner);
@@ -474,29 +549,11 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         n2 += __builtin_popcountll(cm);
     }
     SA_STAMP(5);
-    lds_barrier();
-    SA_STAMP(6);
-    // ---- phase 3: vertical pass of the blur ----
-    if (a.grid_shift && tid < kCells) s_cellbest[tid] = 0;     // (the byte tile is dead from here on)
-    // Blur, vertical pass: 7 taps 18 34 49 55 49 34 18 (8.8 fixed point; each is rounded on its own and
-    // they add up to 257, not 256) down the columns of the split tile; the result fits 16 bits per pixel.  Item = (column group and
-    // parity, 4 output rows): 36 x 8 items.
-    for (int i = tid; !(SA_FAST_SKIP & 2) && i < 2 * kImgDw * (kFastTileH / 4); i += 256) {
-        const int chunk = i / (2 * kImgDw), cp = i - chunk * (2 * kImgDw);
-        const unsigned* src = reinterpret_cast<const unsigned*>(s_eo) + (4 * chunk + 1) * (2 * kEoPitch) + 2 + cp;
-        unsigned pcol[10];
-#pragma unroll
-        for (int j = 0; j < 10; j++) pcol[j] = src[j * 2 * kEoPitch];
-        const us2 k18 = {18, 18}, k34 = {34, 34}, k49 = {49, 49}, k55 = {55, 55};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const us2 s0 = as_us2(pcol[j] + pcol[j + 6]), s1 = as_us2(pcol[j + 1] + pcol[j + 5]),
-                      s2 = as_us2(pcol[j + 2] + pcol[j + 4]), s3 = as_us2(pcol[j + 3]);
-            s_v[(4 * chunk + j) * kVPitch + cp] = as_u32(s0 * k18 + s1 * k34 + s2 * k49 + s3 * k55);
-        }
-    }
+    // ---- phase 3: blur (no LDS written: no barrier in front of it) ----
+    if (!(SA_FAST_SKIP & 2))
+        blur_tile(s_img, wave, tid & 63, a.blur + (size_t)b * a.g.frame_bytes + L.off, (unsigned)L.pitch, x0, y0, h);
     SA_STAMP(7);
-    lds_barrier();
+    lds_barrier();      // every wave's scores are in the score map; the byte tile is dead from here on
     SA_STAMP(8);
     // ---- phase 4a: NMS + border filter over the corner list ----
     // A strict 3x3 maximum has no second one among its 8 neighbours, so a 64 x 32 tile holds at
@@ -508,13 +565,13 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         auto survivor = [&](int k) -> unsigned {
             if (k >= n2) return 0u;
             const unsigned code = my_list2[k] & 0xfffu;
-            const unsigned sr = (code * 1821u) >> 17;            // code / 72 for code < 40 * 72
+            const unsigned sr = staged_row(code);
             const int lx = (int)(code - sr * P) - kImgHalo, ly = (int)sr - kImgHalo;
             const int gx = x0 + lx, gy = y0 + ly;
             if ((unsigned)lx >= (unsigned)kFastTileW || (unsigned)ly >= (unsigned)kFastTileH || gx < edge ||
                 gx >= w - edge || gy < edge || gy >= h - edge)
                 return 0u;
-            const uint8_t* q = s_sc + (code - 6u * sr - (unsigned)(3 * kScPitch + 3));
+            const uint8_t* q = s_sc + (code - (unsigned)(P - kScPitch) * sr - (unsigned)(3 * kScPitch + 3));
             constexpr int S = kScPitch;
             // all nine reads first: one LDS round trip instead of a chain of eight
             const int s = q[0];
@@ -532,6 +589,8 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             return (sv & 0xffff0000u) | (0xffffu - (unsigned)(ly * kFastTileW + lx));
         };
         if (sh) {
+            if (tid < kCells) s_cellbest[tid] = 0;
+            lds_barrier();      // uniform: grid_shift is a kernel argument
             for (int k0 = 0; k0 < n2; k0 += 64) {
                 const unsigned sv = survivor(k0 + (tid & 63));
                 if (sv) { int cell; const unsigned key = cell_key(sv, cell); atomicMax(&s_cellbest[cell], key); }
@@ -555,33 +614,6 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         }
     }
     SA_STAMP(9);
-    // ---- phase 4b: blur, horizontal pass: 4 pixels of one row per item, rows ly and ly + 16 ----
-    // The column sums sit in 16-bit halves, {columns 4g, 4g + 2} and {4g + 1, 4g + 3} per group, so
-    // every tap pair is one 16-bit dot product; min((sum + 2^15) >> 16, 255) is byte 2 of the accumulator:
-    // the taps add up to 257, so a sum can pass 2^24; the accumulator starts at 0xff000000 + 2^15
-    // and the dot products saturate, which turns exactly those sums into 0xffffffff.
-    {
-        uint8_t* blur = a.blur + (size_t)b * a.g.frame_bytes + L.off;
-        const int og = tid & 15, lr = tid >> 4;
-#pragma unroll
-        for (int half = 0; half < ((SA_FAST_SKIP & 2) ? 0 : 2); half++) {
-            const int ly = lr + 16 * half;
-            const int gy = y0 + ly;
-            const uint2* vrow = reinterpret_cast<const uint2*>(s_v + ly * kVPitch) + og;   // group og + 1 is the item's own
-            const uint2 A = vrow[0], B = vrow[1], C = vrow[2];
-            const unsigned rnd = 0xff008000u;
-            // weights as {low half, high half}
-            const unsigned o0 = dot2(A.y, 18u | 49u << 16, dot2(A.x, 34u << 16, dot2(B.x, 55u | 34u << 16, dot2(B.y, 49u | 18u << 16, rnd))));
-            const unsigned o1 = dot2(A.x, 18u << 16, dot2(A.y, 34u << 16, dot2(B.x, 49u | 49u << 16,
-                                dot2(B.y, 55u | 34u << 16, dot2(C.x, 18u, rnd)))));
-            const unsigned o2 = dot2(A.y, 18u << 16, dot2(B.x, 34u | 55u << 16, dot2(B.y, 49u | 49u << 16,
-                                dot2(C.x, 34u, dot2(C.y, 18u, rnd)))));
-            const unsigned o3 = dot2(B.x, 18u | 49u << 16, dot2(B.y, 34u | 55u << 16, dot2(C.x, 49u | 18u << 16, dot2(C.y, 34u, rnd))));
-            // byte 2 of o0 .. o3 -> bytes 0 .. 3
-            const unsigned lo = __builtin_amdgcn_perm(o1, o0, 0x0c0c0602u), hi = __builtin_amdgcn_perm(o3, o2, 0x06020c0cu);
-            if (gy < h && (!(SA_FAST_SKIP & 1) || (lo | hi) == 0x12345678u)) *reinterpret_cast<uint32_t*>(blur + blur_tiled_offset((unsigned)L.pitch, (unsigned)(x0 + 4 * og), (unsigned)gy)) = lo | hi;
-        }
-    }
     SA_STAMP(10);
     lds_barrier();   // the survivor list is complete
     {

@@ -9,7 +9,7 @@ BASE=$(basename $SRC .hip)
 mkdir -p $ROOT/build_variants
 cd $ROOT/slam_amd/csrc
 EXTRA=""
-[ $BASE = match_mfma_kernels ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
+{ [ $BASE = match_mfma_kernels ] || [ $BASE = extract_kernels ]; } && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
 cp $SRC ./variant_tmp_$NAME.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $EXTRA -I. "$@" -c ./variant_tmp_$NAME.hip -o /tmp/variant_$NAME.o
 rm -f ./variant_tmp_$NAME.hip

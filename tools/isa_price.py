@@ -47,7 +47,7 @@ def mix(asm, kernel):
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         s = os.path.join(tmp, "k.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form", "-S",
                         "--cuda-device-only", "-o", s, os.path.join(ROOT, "slam_amd/csrc/extract_kernels.hip")],
                        check=True, stderr=subprocess.DEVNULL)
         asm = open(s).read()
