@@ -68,7 +68,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps) is run this many times; the line reports the median")
-    ap.add_argument("--batch", type=int, default=64, help="frames per step and GPU")
+    ap.add_argument("--batch", type=int, default=128,
+                    help="frames per step and GPU (128: the pyramid's workgroups fill the chip three times exactly and the blurred "
+                         "levels of a batch still fit the Infinity Cache; 64 is 8 % slower per frame, 256 no faster)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=2000)

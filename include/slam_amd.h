@@ -379,7 +379,7 @@ int slam_amd_outlier_flags(slam_amd_matcher* m, const float* xyz, const slam_amd
  *                                                 buffers, valid until _input(p, i + depth)
  * Matches are frameMatch(frame i - 1, frame i, {}, max_dist, area, max_level): queries are the
  * previous frame's keypoints (none for frame 0).
- * create_batched: a slot collects `batch` (1..64) frames and queues them as one upload, one extraction
+ * create_batched: a slot collects `batch` (1..1024) frames and queues them as one upload, one extraction
  * launch sequence, one chained matching call and one download when the last of them is submitted -- a
  * single large frame leaves the chip idle between its short launches, a few per launch fill it; the price
  * is the batch's latency.  Frames are still numbered, filled, submitted and read one by one;

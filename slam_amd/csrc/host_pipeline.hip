@@ -72,7 +72,7 @@ extern "C" int slam_amd_pipeline_create_batched(const slam_amd_orb_params* param
     if (!out) SA_FAIL(SLAM_AMD_ERR_ARG, "out is null");
     *out = nullptr;
     if (depth < 3 || depth > 64) SA_FAIL(SLAM_AMD_ERR_ARG, "depth must be 3..64 (the previous batch's slot must outlive the match)");
-    if (batch < 1 || batch > 64) SA_FAIL(SLAM_AMD_ERR_ARG, "batch must be 1..64");
+    if (batch < 1 || batch > 1024) SA_FAIL(SLAM_AMD_ERR_ARG, "batch must be 1..1024");
     if (capacity <= 0) SA_FAIL(SLAM_AMD_ERR_ARG, "capacity must be positive");
     slam_amd_pipeline* p = new (std::nothrow) slam_amd_pipeline();
     if (!p) SA_FAIL(SLAM_AMD_ERR_NOMEM, "out of host memory");
@@ -89,25 +89,26 @@ extern "C" int slam_amd_pipeline_create_batched(const slam_amd_orb_params* param
         if ((rc = hip(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreateWithFlags"))) return fail(rc);
     p->slots.resize((size_t)depth);
     const size_t img = (size_t)width * height * batch, cap = (size_t)capacity * batch;
+    const size_t cnt = ((size_t)batch * sizeof(int) + 255) / 256 * 256;      // a count per frame of the slot
     for (auto& s : p->slots) {
         if ((rc = hip(hipHostMalloc((void**)&s.h_img, img, hipHostMallocDefault), "hipHostMalloc")) ||
             (rc = hip(hipMalloc((void**)&s.d_img, img), "hipMalloc")) ||
             (rc = hip(hipMalloc((void**)&s.d_kp, cap * sizeof(slam_amd_keypoint)), "hipMalloc")) ||
             (rc = hip(hipMalloc((void**)&s.d_desc, cap * 32), "hipMalloc")) ||
-            (rc = hip(hipMalloc((void**)&s.d_cnt, 256), "hipMalloc")) ||
+            (rc = hip(hipMalloc((void**)&s.d_cnt, cnt), "hipMalloc")) ||
             (rc = hip(hipMalloc((void**)&s.d_match, cap * sizeof(slam_amd_dmatch)), "hipMalloc")) ||
-            (rc = hip(hipMalloc((void**)&s.d_nmatch, 256), "hipMalloc")) ||
+            (rc = hip(hipMalloc((void**)&s.d_nmatch, cnt), "hipMalloc")) ||
             (rc = hip(hipHostMalloc((void**)&s.h_kp, cap * sizeof(slam_amd_keypoint), hipHostMallocDefault), "hipHostMalloc")) ||
             (rc = hip(hipHostMalloc((void**)&s.h_desc, cap * 32, hipHostMallocDefault), "hipHostMalloc")) ||
-            (rc = hip(hipHostMalloc((void**)&s.h_cnt, 256, hipHostMallocDefault), "hipHostMalloc")) ||
+            (rc = hip(hipHostMalloc((void**)&s.h_cnt, cnt, hipHostMallocDefault), "hipHostMalloc")) ||
             (rc = hip(hipHostMalloc((void**)&s.h_match, cap * sizeof(slam_amd_dmatch), hipHostMallocDefault), "hipHostMalloc")) ||
-            (rc = hip(hipHostMalloc((void**)&s.h_nmatch, 256, hipHostMallocDefault), "hipHostMalloc")) ||
+            (rc = hip(hipHostMalloc((void**)&s.h_nmatch, cnt, hipHostMallocDefault), "hipHostMalloc")) ||
             (rc = hip(hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming), "hipEventCreate")) ||
             (rc = hip(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming), "hipEventCreate")) ||
             (rc = hip(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming), "hipEventCreate")) ||
-            (rc = hip(hipMemset(s.d_cnt, 0, 256), "hipMemset")) || (rc = hip(hipMemset(s.d_nmatch, 0, 256), "hipMemset")))
+            (rc = hip(hipMemset(s.d_cnt, 0, cnt), "hipMemset")) || (rc = hip(hipMemset(s.d_nmatch, 0, cnt), "hipMemset")))
             return fail(rc);
-        memset(s.h_cnt, 0, 256); memset(s.h_nmatch, 0, 256);
+        memset(s.h_cnt, 0, cnt); memset(s.h_nmatch, 0, cnt);
     }
     *out = p;
     return SLAM_AMD_OK;

@@ -632,6 +632,9 @@ MatchPlan plan_match_mfma(int batch, int nq_bound, int nt_bound, int n_cu, bool 
     // about three workgroups per CU (one 4K frame, 40 blocks: 38 us in 20 splits, 51 in 12 or 13, 40 in 39).
     const int wgs = p.qblocks * batch;
     int splits = wgs >= 2 * n_cu ? 1 : div_up(3 * n_cu, wgs);
+#ifdef SA_MM_SPLITS
+    splits = SA_MM_SPLITS;      // timing experiments
+#endif
     splits = std::max(1, std::min(splits, div_up(nt_bound, 4 * kMmTile)));
     if (second) splits = std::min(splits, kMaxSecondSplits);
     p.chunk = div_up(div_up(nt_bound, splits), kMmTile) * kMmTile;
