@@ -259,15 +259,17 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     //   s_sc       score map
     //   s_list1    list 1 (phases 1-2)
     //   s_list2    the 6-bit tile (phase 1), then the corner lists, one segment per wave (phases 2-4)
+    //   s_imgc     byte tile, every pixel complemented (phase 2: a darker arc is a brighter arc of the complemented pixels)
     //   s_n        [0] length of list 1, [2] of the survivor list, [3] of list 1 when it is rebuilt with one entry per
     //              pixel, [4] set when the entries per (pixel, polarity) did not fit
     constexpr int kWaves = 4;
     constexpr int kSegEntries = ((kScN + 255) / 256) * 64;     // corners one wave can find: its 64 of every 256 entries
     constexpr int kSegBytes = kSegEntries * 2;
     constexpr int kOffImg = 0, kOffSc = kOffImg + kImgRows * kImgPitch, kOffList1 = kOffSc + kScBytes,
-                  kOffList2 = kOffList1 + kList1Bytes, kOffN = kOffList2 + kWaves * kSegBytes, kLdsBytes = kOffN + 5 * 4;
+                  kOffList2 = kOffList1 + kList1Bytes, kOffImgC = kOffList2 + kWaves * kSegBytes,
+                  kOffN = kOffImgC + kImgRows * kImgPitch, kLdsBytes = kOffN + 5 * 4;
     static_assert(kLdsBytes <= 20480, "LDS of fast_nms");
-    static_assert(kOffSc % 16 == 0 && kOffList1 % 16 == 0 && kOffList2 % 16 == 0 && kOffN % 4 == 0, "LDS alignment");
+    static_assert(kOffSc % 16 == 0 && kOffList1 % 16 == 0 && kOffList2 % 16 == 0 && kOffImgC % 16 == 0 && kOffN % 4 == 0, "LDS alignment");
     __shared__ __align__(16) uint8_t s_mem[kLdsBytes];
     uint8_t* const s_img = s_mem + kOffImg;
     uint8_t* const s_sc = s_mem + kOffSc;
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             const int r = rr + 14 * it;
             if (r < kImgRows) {
                 *reinterpret_cast<uint32_t*>(s_img + r * P + 4 * cg) = v[it];
+                *reinterpret_cast<uint32_t*>(s_img + (kOffImgC - kOffImg) + r * P + 4 * cg) = ~v[it];
                 s_q[r * kQPitch + 1 + cg] = (v[it] >> 2) & 0x3f3f3f3fu;
             }
         }
@@ -489,12 +492,13 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     // The score -- the largest threshold that still detects: the best arc's smallest difference, minus one -- says
     // whether the pixel is a corner at all (best > t), so it is computed for every listed position while its ring
     // is in registers: the corners need no second round of gathers.  A darker corner has no brighter arc and vice
-    // versa: one polarity per entry.  With e[j] = centre - ring pixel j a darker arc has all e > t; a brighter one
-    // all -e > t, tested as e ^ -1 = -e - 1 (one xor per pixel selects the polarity per lane) with the 1 put back at
-    // the end.  The 16 arcs of 9 pixels share their middles: arc k and arc k + 1 (k even) are pixels k + 1 .. k + 8
-    // plus pixel k or pixel k + 9, and those middles are built from 8 pair minima -- 56 two-operand minima and maxima
-    // in all, issued as 16-bit operations (differences fit 10 bits), which run at twice the rate of the 32-bit and
-    // three-operand forms.
+    // versa: one polarity per entry.  Minima and maxima commute with subtracting the centre, so the arcs are
+    // evaluated on the ring pixels themselves: for a brighter corner, best = (largest over the 16 arcs of the
+    // smallest pixel of the arc) - centre; a darker corner is a brighter one of the complemented tile, which
+    // lies in LDS too, so a lane only picks the tile it reads from -- no subtraction, no complement per ring pixel.
+    // The 16 arcs of 9 pixels share their middles: arc k and arc k + 1 (k even) are pixels k + 1 .. k + 8
+    // plus pixel k or pixel k + 9 (the larger of the two decides), and those middles are built from 8 pair minima -- 48 two-operand minima and maxima
+    // in all, issued as 16-bit operations, which run at twice the rate of the 32-bit and three-operand forms.
     // Corners go to a list per wave (the wave that found them also suppresses them): its length stays in a scalar
     // register, and appending takes a ballot and a lane count, no atomic.
     const int wave = tid >> 6;
@@ -509,34 +513,31 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
             // odd = darker; an entry of a rebuilt list has bit 0 = darker, bit 15 = brighter
             const unsigned e = s_list1[k];
             code = ((e >> 3) & 0xffcu) + ((e >> 1) & 3u) * (unsigned)(14 * P) + ((e >> 3) & 3u);
-            const uint8_t* p = s_img + code;
             constexpr int off[16] = SA_RING_OFFSETS(P);
-            int ev[16];
-            const int v = p[0];
-#pragma unroll
-            for (int j = 0; j < 16; j++) ev[j] = v - (int)p[off[j]];
-            auto arc_best = [&](int m) {       // m = 0: darker arcs, -1: brighter arcs; returns the best arc's minimum (clamped at -1)
+            auto arc_best = [&](unsigned brighter) {
+                const uint8_t* p = s_img + code + (brighter ? 0u : (unsigned)(kOffImgC - kOffImg));
                 short d[16];
 #pragma unroll
-                for (int j = 0; j < 16; j++) d[j] = (short)(ev[j] ^ m);
+                for (int j = 0; j < 16; j++) d[j] = (short)p[off[j]];
+                const int centre = p[0];
                 short pm[8], qm[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) pm[i] = min16(d[2 * i + 1], d[(2 * i + 2) & 15]);
 #pragma unroll
                 for (int i = 0; i < 8; i++) qm[i] = min16(pm[i], pm[(i + 1) & 7]);
-                short best = -1;
+                short best = 0;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const short core = min16(qm[i], qm[(i + 2) & 7]);        // pixels 2i + 1 .. 2i + 8
-                    best = max16(best, max16(min16(core, d[2 * i]), min16(core, d[(2 * i + 9) & 15])));
+                    best = max16(best, min16(core, max16(d[2 * i], d[(2 * i + 9) & 15])));      // the better of arcs 2i and 2i + 1
                 }
-                return (int)best - m;
+                return (int)best - centre;
             };
             pol = e & 1u ? 0u : 1u;     // darker where the entry says so
-            int best = arc_best(pol ? -1 : 0);
+            int best = arc_best(pol);
             if (merged && best <= t && (e & 0x8001u) == 0x8001u) {   // an entry of a rebuilt list with both flags
                 pol = 1u;
-                best = arc_best(-1);
+                best = arc_best(1u);
             }
             corner = best > t;
             if (corner) {
