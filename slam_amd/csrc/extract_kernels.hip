@@ -208,10 +208,11 @@ constexpr BlurTaps make_blur_taps() {
 __device__ const BlurTaps c_blur_taps = make_blur_taps();
 typedef int blur_v4i __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void blur_tile(const uint8_t* s_img, int wave, int lane, uint8_t* blur_level, unsigned pitch, int x0, int y0, int h) {
+// th, tv: the lane's taps of the two passes, c_blur_taps.h[lane][0..3] and c_blur_taps.v[lane][0..1] (dwords 2 and 3 of the
+// latter are zero) -- loaded by the caller at the start of the kernel, where the tile's own loads hide the latency
+__device__ __forceinline__ void blur_tile(const uint8_t* s_img, int wave, int lane, const uint4& th, const uint2& tv,
+                                          uint8_t* blur_level, unsigned pitch, int x0, int y0, int h) {
     const int n = lane & 15, kg = lane >> 4;
-    const uint4 th = *reinterpret_cast<const uint4*>(&c_blur_taps.h[lane][0]);
-    const uint2 tv = *reinterpret_cast<const uint2*>(&c_blur_taps.v[lane][0]);      // dwords 2 and 3 are zero
     const blur_v4i bh = {(int)th.x, (int)th.y, (int)th.z, (int)th.w};
     // ---- horizontal: H row hr = 16 m + n is staged row hr + 1 (rows past the staged tile are never used: clamped) ----
     unsigned lo[3], hi[3];
@@ -328,6 +329,9 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     const int tid = threadIdx.x;
     SA_STAMP_DECL;
     SA_STAMP(0);
+    // the blur's taps of this lane, on their way while the tile is staged
+    const uint4 blur_th = *reinterpret_cast<const uint4*>(&c_blur_taps.h[tid & 63][0]);
+    const uint2 blur_tv = *reinterpret_cast<const uint2*>(&c_blur_taps.v[tid & 63][0]);
     if (tid < 5) s_n[tid] = 0;
     if (tid < kScBytes / 16) reinterpret_cast<uint4*>(s_sc)[tid] = make_uint4(0u, 0u, 0u, 0u);
     // Thread (column group cg, row rr) of an 18 x 14 arrangement: one dword column
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     SA_STAMP(5);
     // ---- phase 3: blur (no LDS written: no barrier in front of it) ----
     if (!(SA_FAST_SKIP & 2))
-        blur_tile(s_img, wave, tid & 63, a.blur + (size_t)b * a.g.frame_bytes + L.off, (unsigned)L.pitch, x0, y0, h);
+        blur_tile(s_img, wave, tid & 63, blur_th, blur_tv, a.blur + (size_t)b * a.g.frame_bytes + L.off, (unsigned)L.pitch, x0, y0, h);
     SA_STAMP(7);
     lds_barrier();      // every wave's scores are in the score map; the byte tile is dead from here on
     SA_STAMP(8);
