@@ -41,7 +41,7 @@ def timed(label, fn, cmp_count, stages=("match", "spatial_sort", "match_window",
 
 
 # ---- 64 frames of 640x480, as the extractor leaves them (sorted by octave, real positions) ----
-W, H, B, CAP = 640, 480, 64, 4096
+W, H, B, CAP = 640, 480, int(os.environ.get("SA_BENCH_BATCH", "64")), 4096
 ex = capi.Extractor(capi.orb_params(nfeatures=2000), W, H, max_batch=B, max_keypoints=CAP)
 frames = synth.frame_sequence(W, H, B, seed=1)
 d_img = torch.from_numpy(np.stack(frames)).to(dev)
@@ -63,7 +63,7 @@ for area, lvl in ((-1.0, -1), (-1.0, 4), (-1.0, 3), (50.0, 4), (50.0, -1)):
         m.frame_match_chain_async(B, desc.data_ptr() + last * CAP * 32, kp.data_ptr() + last * CAP * KP,
                                   cnt.data_ptr() + 4 * last, desc.data_ptr(), kp.data_ptr(), CAP, cnt.data_ptr(),
                                   out, nout, max_dist=300.0, area=area, max_level=lvl, stream=st)
-    timed("64 frames chained  area=%g max_level=%d" % (area, lvl), chain, cmp_frames)
+    timed("%d frames chained  area=%g max_level=%d" % (B, area, lvl), chain, cmp_frames)
     print("    matches per frame: %.1f" % float(nout.cpu().numpy().mean()))
 mr = capi.Matcher()
 mr.debug_set_sweep_kernel(kernel)
@@ -74,7 +74,7 @@ for area, lvl in ((-1.0, -1), (-1.0, 4)):
         mr.frame_match_chain_async(B, desc.data_ptr() + last * CAP * 32, kp.data_ptr() + last * CAP * KP,
                                    cnt.data_ptr() + 4 * last, desc.data_ptr(), kp.data_ptr(), CAP, cnt.data_ptr(),
                                    out, nout, max_dist=300.0, area=area, max_level=lvl, stream=st)
-    timed("64 frames chained ratio 0.8  area=%g lvl=%d" % (area, lvl), chain_r, cmp_frames)
+    timed("%d frames chained ratio 0.8  area=%g lvl=%d" % (B, area, lvl), chain_r, cmp_frames)
 ex.close(); mr.close()
 if only_frames:
     m.close()
