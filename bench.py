@@ -782,21 +782,51 @@ def run_projection(args):
         ex.extract_batch_async(d_frames[i % 4], 1, 0, W, d_kp, d_desc, d_cnt, CAP, st)
         m.frame_match_async(q_desc, q_kp, NQ, None, d_desc, d_kp, CAP, d_cnt, d_out, d_n, d_ids=ids, n_ids=NQ,
                             d_q_xy=q_xy, max_dist=300.0, area=50.0, max_level=4, stream=st)
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 4)):
         step(i)
+    # eager pass with per-stage events (stage times)
     capi.prof_enable(args.steps * 12 + 16)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt_eager = time.perf_counter() - t0
     stages = capi.prof_collect()
+    capi.prof_enable(0)
+    # timed region: the same step as one HIP graph per input frame, replayed in turn (one frame's six launches
+    # are short next to the gaps between eager launches)
+    dt, mode = dt_eager, "eager"
+    if not args.no_graph:
+        try:
+            graphs = []
+            side = torch.cuda.Stream(device=dev)
+            for i in range(4):
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    st = side.cuda_stream
+                    step(i)
+                graphs.append(g)
+            st = torch.cuda.current_stream().cuda_stream
+            for i in range(8):
+                graphs[i % 4].replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                graphs[i % 4].replay()
+            torch.cuda.synchronize()
+            dt, mode = time.perf_counter() - t0, "hip graph replay"
+        except Exception as e:
+            st = torch.cuda.current_stream().cuda_stream
+            sys.stderr.write("graph capture failed (%s); the eager timing is reported\n" % e)
     n_t = int(d_cnt.item())
     print(json.dumps({
         "metric": "frames/s ORB extract + projection-windowed match @1241x376 4k feats vs 20k map points",
         "unit": "frames/s", "value": round(args.steps / dt, 2), "n_gpus": 1, "steps": args.steps,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "keypoints": n_t, "matches": int(d_n.item()),
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "launch_mode": mode,
+        "ms_per_step_eager_with_stage_events": round(dt_eager / args.steps * 1e3, 4),
+        "keypoints": n_t, "matches": int(d_n.item()),
         "match_stage_us": round(sum(stages[k][0] / stages[k][1] for k in ("match", "spatial_sort", "match_window")
                                     if k in stages) * 1e3, 2),
         "equivalent_full_sweep_gcmp_per_s": round(NQ * n_t / sum(
