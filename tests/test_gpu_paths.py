@@ -471,3 +471,29 @@ def test_frame_pipeline_matches_sequential_oracle(oracle, capi, batch):
             ref = oracle.match_gated(prev[1], prev[0], d_o, kp_o, 300.0, 50.0, 4)
             assert mt.tobytes() == ref.tobytes(), i
         prev = (kp_o, d_o)
+
+
+def test_frame_pipeline_slots_of_more_than_64_frames(oracle, capi):
+    """Slots of 72 frames (the per-slot counts used to be a fixed 64-entry array): 150 frames of a short sequence
+    repeated, two full slots and a flushed one; every frame's results equal those of the one-frame-per-slot pipeline,
+    and three of them (first of a slot, last of a slot, in the flushed slot) equal the oracle's."""
+    from slam_amd.stream import FramePipeline
+    W, H, NF, N = 160, 120, 150, 150
+    base = synth.frame_sequence(W, H, 6, seed=9)
+    frames = [base[i % 6] for i in range(N)]
+    res = {}
+    for batch in (1, 72):
+        pipe = FramePipeline(W, H, capi.orb_params(nfeatures=NF), 512, depth=3, batch=batch, max_dist=300.0, area=-1.0, max_level=4)
+        res[batch] = pipe.run(frames, keep_results=True)
+        pipe.close()
+    assert len(res[1]) == N and len(res[72]) == N
+    for i in range(N):
+        for a, b in zip(res[1][i], res[72][i]):
+            assert a.tobytes() == b.tobytes(), i
+    po = oracle.params(nfeatures=NF)
+    for i in (72, 143, 149):
+        kp_p, d_p = oracle.detect_and_compute(po, frames[i - 1])
+        kp_o, d_o = oracle.detect_and_compute(po, frames[i])
+        kp, d, mt = res[72][i]
+        assert kp.tobytes() == kp_o.tobytes() and np.array_equal(d, d_o), i
+        assert mt.tobytes() == oracle.match_gated(d_p, kp_p, d_o, kp_o, 300.0, -1.0, 4).tobytes(), i
