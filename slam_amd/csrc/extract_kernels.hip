@@ -25,7 +25,8 @@
 #endif
 #ifndef SA_FAST_SKIP
 #define SA_FAST_SKIP 0    // timing experiments only (results are wrong): 1 no blur store, 2 no blur at all, 4 no ring test / score /
-#endif                    // suppression (list 1 taken as empty), 8 no compass test either, 16 tile not loaded from memory
+#endif                    // suppression (list 1 taken as empty), 8 no compass test either, 16 tile not loaded from memory,
+                          // 32 the blur's matrix products replaced by vector additions
 #if SA_FAST_EXP
 #define SA_STAMP_DECL unsigned long long stamp_[16] = {}
 #define SA_STAMP(i) stamp_[i] = __builtin_amdgcn_s_memtime()
@@ -179,7 +180,7 @@ static_assert(kImgPitch == 80, "staged_row divides by the pitch of the staged ti
 // and column l & 15 of B, 16 of the 64 k each: k group l >> 4, and D[4 (l >> 4) + i][l & 15] in register i).
 // Wave w takes the columns 16 w .. 16 w + 15 of the tile:
 //   horizontal  H[r][c] = sum_t tap[t] p[r][c - 3 + t] for the 38 rows the vertical pass needs, as three products
-//               of 16 rows: A = 16 bytes of a staged row per lane (pixels - 128: the product is signed), B[k][n] =
+//               of 16 rows: A = 16 bytes of a staged row per lane (staged as pixel - 128: the product is signed), B[k][n] =
 //               tap[k - n - 1], C = 128 * 257, so that D = H, 16 bits.  A lane ends up with H of ONE column, rows
 //               16 m + 4 (l >> 4) + i in register i of product m.
 //   vertical    out[r][c] = sum_t tap[t] H[r + t][c] sums over the row index of H, which lies in the registers of a
@@ -222,8 +223,8 @@ __device__ __forceinline__ void blur_tile(const uint8_t* s_img, int wave, int la
         const int row = min(16 * m + n + 1, kImgRows - 1);
         uint4 p = make_uint4(0u, 0u, 0u, 0u);
         if (kg < 2) p = *reinterpret_cast<const uint4*>(s_img + row * kImgPitch + 16 * wave + 16 * kg);   // (taps of k >= 23 are zero)
-        const blur_v4i av = {(int)(p.x ^ 0x80808080u), (int)(p.y ^ 0x80808080u), (int)(p.z ^ 0x80808080u), (int)(p.w ^ 0x80808080u)};
-        const blur_v4i d = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bh, c_h, 0, 0, 0);
+        const blur_v4i av = {(int)p.x, (int)p.y, (int)p.z, (int)p.w};       // signed bytes: pixel - 128
+        const blur_v4i d = (SA_FAST_SKIP & 32) ? av + bh + c_h : __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bh, c_h, 0, 0, 0);
         // bytes 0 and 1 of the four results -> one dword each, as signed bytes
         const unsigned p01 = __builtin_amdgcn_perm((unsigned)d.y, (unsigned)d.x, 0x05010400u);   // lo0 lo1 hi0 hi1
         const unsigned p23 = __builtin_amdgcn_perm((unsigned)d.w, (unsigned)d.z, 0x05010400u);
@@ -237,8 +238,8 @@ __device__ __forceinline__ void blur_tile(const uint8_t* s_img, int wave, int la
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         const blur_v4i bv = half == 0 ? blur_v4i{(int)tv.x, (int)tv.y, 0, 0} : blur_v4i{0, (int)tv.x, (int)tv.y, 0};
-        const blur_v4i dl = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_lo, bv, c_v, 0, 0, 0);
-        const blur_v4i dh = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hi, bv, c_0, 0, 0, 0);
+        const blur_v4i dl = (SA_FAST_SKIP & 32) ? a_lo + bv + c_v : __builtin_amdgcn_mfma_i32_16x16x64_i8(a_lo, bv, c_v, 0, 0, 0);
+        const blur_v4i dh = (SA_FAST_SKIP & 32) ? a_hi + bv : __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hi, bv, c_0, 0, 0, 0);
         unsigned v[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) v[i] = ((unsigned)dh[i] << 8) + (unsigned)dl[i];       // < 2^24 + 2^17
@@ -256,11 +257,11 @@ __device__ __forceinline__ void blur_tile(const uint8_t* s_img, int wave, int la
 __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
     // One block of LDS carved by hand (separately declared arrays get padded and ordered by the compiler, and four
     // bytes too many cost a workgroup per CU: 8 workgroups need 160 KB / 8 each; 7 are 4 % slower, 5 27 %).
-    //   s_img      byte tile                                  (dead after phase 3; then: grid cells, survivor list)
+    //   s_img      byte tile, pixel - 128 as signed bytes      (dead after phase 3; then: grid cells, survivor list)
     //   s_sc       score map
     //   s_list1    list 1 (phases 1-2)
     //   s_list2    the 6-bit tile (phase 1), then the corner lists, one segment per wave (phases 2-4)
-    //   s_imgc     byte tile, every pixel complemented (phase 2: a darker arc is a brighter arc of the complemented pixels)
+    //   s_imgc     byte tile, 127 - pixel as signed bytes      (phase 2: a darker arc is a brighter arc of the complemented pixels)
     //   s_n        [0] length of list 1, [2] of the survivor list, [3] of list 1 when it is rebuilt with one entry per
     //              pixel, [4] set when the entries per (pixel, polarity) did not fit
     constexpr int kWaves = 4;
@@ -378,8 +379,10 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
         for (int it = 0; it < 3; it++) {
             const int r = rr + 14 * it;
             if (r < kImgRows) {
-                *reinterpret_cast<uint32_t*>(s_img + r * P + 4 * cg) = v[it];
-                *reinterpret_cast<uint32_t*>(s_img + (kOffImgC - kOffImg) + r * P + 4 * cg) = ~v[it];
+                // both byte tiles hold signed bytes: pixel - 128 (what the blur's signed products take as they stand)
+                // and 127 - pixel
+                *reinterpret_cast<uint32_t*>(s_img + r * P + 4 * cg) = v[it] ^ 0x80808080u;
+                *reinterpret_cast<uint32_t*>(s_img + (kOffImgC - kOffImg) + r * P + 4 * cg) = v[it] ^ 0x7f7f7f7fu;
                 s_q[r * kQPitch + 1 + cg] = (v[it] >> 2) & 0x3f3f3f3fu;
             }
         }
@@ -522,14 +525,14 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(FastArgs a) {
                 const uint8_t* p = s_img + code + (brighter ? 0u : (unsigned)(kOffImgC - kOffImg));
                 short d[16];
 #pragma unroll
-                for (int j = 0; j < 16; j++) d[j] = (short)p[off[j]];
-                const int centre = p[0];
+                for (int j = 0; j < 16; j++) d[j] = (short)(int8_t)p[off[j]];
+                const int centre = (int8_t)p[0];
                 short pm[8], qm[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) pm[i] = min16(d[2 * i + 1], d[(2 * i + 2) & 15]);
 #pragma unroll
                 for (int i = 0; i < 8; i++) qm[i] = min16(pm[i], pm[(i + 1) & 7]);
-                short best = 0;
+                short best = -128;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const short core = min16(qm[i], qm[(i + 2) & 7]);        // pixels 2i + 1 .. 2i + 8
