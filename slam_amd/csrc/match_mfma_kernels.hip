@@ -96,7 +96,7 @@ __device__ __forceinline__ void acc_fail(v16f& acc, int i) { const float f = acc
 
 #ifdef SA_MM_STAMPS
 // Diagnostic build only: per wave, the shader clock at four points of the kernel, the hardware id and the real-time clock.
-__device__ unsigned long long g_mm_stamps[8192][6];
+__device__ unsigned long long g_mm_stamps[8192][10];      // 0-3: start, loop, last tile, end; 4: hardware id; 5: real time; 6-9: steps of the prologue
 #define SA_STAMP(slot) do { if (lane == 0) g_mm_stamps[(blockIdx.x * 4 + wave) & 8191][slot] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SA_STAMP(slot) do { } while (0)
@@ -108,8 +108,11 @@ __device__ __forceinline__ constexpr int acc_row(int i, int h) { return 8 * (i >
 // SECOND: also keep the second smallest key (for the ratio test); every split then stores its
 // (best, second) pair and the finalize kernel merges the splits.
 // AREA / LEVEL: the window and octave gates.
+#ifndef SA_MM_UNGATED_WGS
+#define SA_MM_UNGATED_WGS 3     // workgroups per CU of the variants without a gate (timing experiments: 2)
+#endif
 template <bool PAIRS, bool SECOND, bool AREA, bool LEVEL>
-__global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : 3) void match_mfma_kernel(MatchArgs a) {
+__global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : SA_MM_UNGATED_WGS) void match_mfma_kernel(MatchArgs a) {
     __shared__ uint4 s_tile[3][kMmBT * kMmSubU4];
     // per tile, four deep: the rows' positions (x, then y) and per block of 32 rows the mask of the rows with
     // octave > max_level
@@ -162,8 +165,13 @@ __global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : 3) void match_mfma_
     }
 #endif
 
-    // ---- train tile staging: thread (d, tr) expands dword d of train rows tr, tr + 32 ... of a tile.  With a gate on,
-    //      wave w also fetches what the gates need of block w: lane l the x (l < 32) or y of row l % 32, and its octave ----
+    // ---- train tile staging, two shapes that fill the same LDS image.  In the tile loop thread (d, tr) expands dword d of
+    //      train rows tr, tr + 32 ... of a tile: four independent dwords, each fetched right after the one before it was
+    //      expanded.  The first two tiles, which the prologue fetches and expands in one go, are taken as 16 bytes per
+    //      thread instead -- thread (block w = wave, row r, half h) gets dwords 4 h .. 4 h + 3 of row 32 w + r, a wave's
+    //      load covers 1 KB without a gap -- because every workgroup of a launch starts at the same time and their loads
+    //      queue up in the address units (a quarter of the instructions for the same bytes).  With a gate on, wave w also
+    //      fetches what the gates need of block w: lane l the x (l < 32) or y of row l % 32, and its octave ----
     static_assert(kMmBT == 4, "one wave per block of a tile stages the block's keypoint data");
     const int sd = tid >> 5, tr = tid & 31;
     constexpr bool kMeta = AREA || LEVEL;
@@ -177,6 +185,11 @@ __global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : 3) void match_mfma_
     const unsigned my_off = (unsigned)tr * 32u + (unsigned)sd * 4u, bound_off = bound_row * 32u + (unsigned)sd * 4u;
     auto load_row = [&](int t0, int k, Staged& s) {
         s.w[k] = *reinterpret_cast<const unsigned*>(tdesc_base + min(my_off + (unsigned)(t0 + k * kMmSub) * 32u, bound_off));
+    };
+    const unsigned my_row = (unsigned)(wave * kMmSub + r);
+    auto load_rows16 = [&](int t0, Staged& s) {      // w[j]: dword 4 h + j of row 32 wave + r
+        const uint4 v = *reinterpret_cast<const uint4*>(tdesc_base + (min((unsigned)t0 + my_row, bound_row) * 32u + (unsigned)h * 16u));
+        s.w[0] = v.x; s.w[1] = v.y; s.w[2] = v.z; s.w[3] = v.w;
     };
     auto load_meta = [&](int t0, Staged& s) {
         if (!kMeta) return;
@@ -213,9 +226,9 @@ __global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : 3) void match_mfma_
             s_high[mb][wave] = (unsigned)mask;
         }
     };
-    auto stage_tile = [&](int buf, const Staged& s) {
+    auto stage_tile16 = [&](int buf, const Staged& s) {       // a tile fetched by load_rows16
 #pragma unroll
-        for (int k = 0; k < kMmBT; k++) *stage_slot(buf, k) = expand_train(s.w[k]);
+        for (int j = 0; j < 4; j++) s_tile[buf][wave * kMmSubU4 + (4 * h + j) * 32 + r] = expand_train(s.w[j]);
     };
     // this lane's operand of block k, product s of a buffer
     auto operand = [&](int buf, int k, int s) { return *reinterpret_cast<const v4i*>(&s_tile[buf][k * kMmSubU4 + s * 64 + h * 32 + r]); };
@@ -234,8 +247,14 @@ __global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : 3) void match_mfma_
         qidx[b] = qi;
         const int qc = min(qi, nq_bound - 1);
         const size_t row = qs.base + (size_t)((!PAIRS && a.ids) ? a.ids[qc] : qc);
+        // 16 bytes of the row per lane half (dwords 4 h .. 4 h + 3); the two dwords the other half needs are swapped below
+#ifdef SA_MM_QOLD
 #pragma unroll
         for (int s = 0; s < kMmSteps; s++) qw[b][s] = reinterpret_cast<const unsigned*>(qs.desc + row * 32)[2 * s + h];
+#else
+        const uint4 own = *reinterpret_cast<const uint4*>(qs.desc + row * 32 + 16 * h);
+        qw[b][0] = own.x; qw[b][1] = own.y; qw[b][2] = own.z; qw[b][3] = own.w;
+#endif
         qx[b] = qy[b] = 0.f;
         qoct[b] = 0;
         if (AREA) {
@@ -251,11 +270,29 @@ __global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : 3) void match_mfma_
     }
     // (after the queries: a gather through ids waits for every load before it)
     Staged g, g0, g1;
-    load_tile(t_begin, g0);
-    load_tile(t_begin + kMmTile, g1);
+    load_rows16(t_begin, g0);
+    load_meta(t_begin, g0);
+    load_rows16(t_begin + kMmTile, g1);
+    load_meta(t_begin + kMmTile, g1);
     load_tile(t_begin + 2 * kMmTile, g);
+    SA_STAMP(6);      // every load of the prologue is on its way
     if (qblock * kMmQueries >= nq || t_begin >= t_end) return;
+    SA_STAMP(7);      // the counts have arrived
 
+    // product s takes dword 2 s + h: half 0 holds dwords 0 .. 3 and needs 0, 2 (its own) and 4, 6 (the other half's
+    // first and third); half 1 holds 4 .. 7 and needs 1, 3 (the other half's second and fourth) and 5, 7 (its own)
+#ifndef SA_MM_QOLD
+#pragma unroll
+    for (int b = 0; b < kMmNB; b++) {
+        const unsigned give0 = h ? qw[b][0] : qw[b][1], give1 = h ? qw[b][2] : qw[b][3];
+        const unsigned take0 = (unsigned)__shfl_xor((int)give0, 32, 64), take1 = (unsigned)__shfl_xor((int)give1, 32, 64);
+        const unsigned o0 = qw[b][0], o1 = qw[b][1], o2 = qw[b][2], o3 = qw[b][3];
+        qw[b][0] = h ? take0 : o0;
+        qw[b][1] = h ? take1 : o2;
+        qw[b][2] = h ? o1 : take0;
+        qw[b][3] = h ? o3 : take1;
+    }
+#endif
     // ---- queries of this wave: expanded once ----
     v4i bq[kMmNB][kMmSteps];
     int pq[kMmNB];      // popcount of the whole query descriptor
@@ -277,6 +314,7 @@ __global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : 3) void match_mfma_
         }
         pq[b] = pc + __shfl_xor(pc, 32, 64);
     }
+    SA_STAMP(8);      // queries expanded
     // bounding box of this wave's queries (both lane halves hold the same 32 per query block): a block of train rows
     // whose own box lies a window or more away in x or in y cannot pass the window gate with any of them
     float qbox[4] = {0.f, 0.f, 0.f, 0.f};      // x min, x max, y min, y max
@@ -460,9 +498,9 @@ __global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : 3) void match_mfma_
     // registers already.  What a block's gates need of its tile's metadata is read up to one tile later, hence
     // four metadata buffers.
     const int n_tiles = (t_end - t_begin + kMmTile - 1) / kMmTile;
-    stage_tile(0, g0);
+    stage_tile16(0, g0);
     stage_meta(0, g0);
-    stage_tile(1, g1);
+    stage_tile16(1, g1);
     stage_meta(1, g1);
     lds_barrier();
 
@@ -470,6 +508,7 @@ __global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : 3) void match_mfma_
     // they fall free (slot 2s + 1 is the last to use operand s), which leaves room for a third wave per SIMD; with
     // gates two sets in turn, the next block's read in the first slots (the gate code in the later slots wants the
     // LDS to itself, and two waves per SIMD is all the registers allow there anyway).
+    SA_STAMP(9);      // two tiles staged, first barrier passed
     v4i af0[kMmSteps], af1[kMmSteps];
 #pragma unroll
     for (int s = 0; s < kMmSteps; s++) af0[s] = operand(0, 0, s);
@@ -614,7 +653,7 @@ __global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : 3) void match_mfma_
 
 #ifdef SA_MM_STAMPS
 extern "C" int slam_amd_debug_mm_stamps(unsigned long long* out, int n_waves) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mm_stamps), (size_t)n_waves * 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mm_stamps), (size_t)n_waves * 10 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -33,7 +33,7 @@ for it in range(6):     # like the benchmark step: extraction, then the chained 
                               out, nout, max_dist=300.0, area=-1.0, max_level=-1, stream=st)
 torch.cuda.synchronize()
 n = 2048
-buf = np.zeros((n, 6), np.uint64)
+buf = np.zeros((n, 10), np.uint64)
 lib = capi.lib()
 lib.slam_amd_debug_mm_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.slam_amd_debug_mm_stamps(buf.ctypes.data, n) == 0
@@ -45,6 +45,10 @@ print("waves", n, "keypoints", cnt.cpu().numpy()[:4])
 pro, loop, tail = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
 for name, v in (("prologue", pro), ("tile loop", loop), ("last tile + output", tail), ("whole wave", t[:, 3] - t[:, 0])):
     print("%-20s cycles: min %7d  median %7d  p90 %7d  max %7d" % (name, v.min(), np.median(v), np.percentile(v, 90), v.max()))
+pt = buf[:, 6:10].astype(np.int64)
+for name, v in (("  loads issued", pt[:, 0] - t[:, 0]), ("  counts arrived", pt[:, 1] - pt[:, 0]), ("  queries expanded", pt[:, 2] - pt[:, 1]),
+                ("  tiles staged + barrier", pt[:, 3] - pt[:, 2]), ("  operands read", t[:, 1] - pt[:, 3])):
+    print("%-26s cycles: min %7d  median %7d  p90 %7d  max %7d" % (name, v.min(), np.median(v), np.percentile(v, 90), v.max()))
 print("real-time clock at wave start (10 ns ticks): spread %d" % (rt.max() - rt.min()))
 # shader clocks are per XCD: compare within a wave only.  Start skew in real time:
 order = np.argsort(rt)
