@@ -759,12 +759,30 @@ __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompa
     // Workgroups go round-robin over the 8 XCDs; the level is rotated by the frame so that every XCD
     // gets all levels (with 8 levels and level = blockIdx % 8, one XCD would get every frame's level 0,
     // the longest lists, and another every frame's top level).
+    // One workgroup per level: the lower levels, with the long lists, come first in the grid and the top quarter of the
+    // levels last.  Three workgroups fit a CU; when the grid is more than one round of them (128 frames x 8 levels are
+    // 1.33), the workgroups that start late are the short ones and the launch ends with them instead of with a second
+    // level-0 list (22 -> 13 us at 128 frames).
     const int bands = kBanded ? a.g.bands : 1;
     const int per_frame = a.g.nlevels * bands;
-    const int b = blockIdx.x / per_frame;
-    const int in_frame = (int)blockIdx.x - b * per_frame;
-    const int band = kBanded ? in_frame / a.g.nlevels : 0;          // the band of tile rows this workgroup selects from (one band: the level)
-    const int my_level = (in_frame - band * a.g.nlevels + b) % a.g.nlevels;
+    int b, band = 0, my_level;
+    if (kBanded) {
+        b = blockIdx.x / per_frame;
+        const int in_frame = (int)blockIdx.x - b * per_frame;
+        band = in_frame / a.g.nlevels;          // the band of tile rows this workgroup selects from
+        my_level = (in_frame - band * a.g.nlevels + b) % a.g.nlevels;
+    } else {
+        const int n_low = a.g.nlevels - a.g.nlevels / 4, n_top = a.g.nlevels - n_low;      // 6 + 2 of 8 levels
+        const int frames = (int)gridDim.x / a.g.nlevels, low_groups = frames * n_low;
+        if ((int)blockIdx.x < low_groups) {
+            b = blockIdx.x / n_low;
+            my_level = ((int)blockIdx.x - b * n_low + b) % n_low;
+        } else {
+            const int j = (int)blockIdx.x - low_groups;
+            b = j / n_top;
+            my_level = n_low + (j - b * n_top + b) % n_top;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if SA_SEL_STAMPS
     unsigned long long sst[6] = {};
