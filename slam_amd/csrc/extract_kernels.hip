@@ -762,7 +762,8 @@ __global__ __launch_bounds__(kSelThreads) void select_compact_kernel(SelectCompa
     // One workgroup per level: the lower levels, with the long lists, come first in the grid and the top quarter of the
     // levels last.  Three workgroups fit a CU; when the grid is more than one round of them (128 frames x 8 levels are
     // 1.33), the workgroups that start late are the short ones and the launch ends with them instead of with a second
-    // level-0 list (22 -> 13 us at 128 frames).
+    // level-0 list (24 -> 22.5 us at 128 frames: the workgroups of a CU share its LDS and issue slots, so most of the time is
+    // throughput, not the tail).
     const int bands = kBanded ? a.g.bands : 1;
     const int per_frame = a.g.nlevels * bands;
     int b, band = 0, my_level;
