@@ -1468,11 +1468,16 @@ __global__ __launch_bounds__(64) void describe_kernel(DescribeArgs a) {
             const unsigned pitch8 = (unsigned)__builtin_amdgcn_readlane(bpitch, j) * 8u;   // bytes from one tile row to the next
             const int rows = __builtin_amdgcn_readlane(yshift, j) + kBRows;               // rows of the fetch that the patch reaches
             const unsigned at = ((brow & 8) ? pitch8 : 0u) + 128u * (unsigned)bchunk + 16u * (unsigned)(brow & 7);
+            // the fourth 16-byte column is only reached by a patch that starts in the last 4 bytes of the first one:
+            // otherwise its quads of lanes stay out of the loads (a quarter of what they cost the address unit)
+            const bool col = 16 * bchunk < __builtin_amdgcn_readlane(bshift, j) + kBRows;
             PatchRegs r;
-            r.v0 = *(global_u4_t)(base + at);
-            r.v1 = *(global_u4_t)(base + (at + 2u * pitch8));
-            r.v2 = u32x4{0u, 0u, 0u, 0u};
-            if (32 + brow < rows) r.v2 = *(global_u4_t)(base + (at + 4u * pitch8));
+            r.v0 = r.v1 = r.v2 = u32x4{0u, 0u, 0u, 0u};
+            if (col) {
+                r.v0 = *(global_u4_t)(base + at);
+                r.v1 = *(global_u4_t)(base + (at + 2u * pitch8));
+                if (32 + brow < rows) r.v2 = *(global_u4_t)(base + (at + 4u * pitch8));
+            }
             return r;
         };
         // LDS traffic of one wave executes in order; this only keeps the compiler from moving LDS

@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from slam_amd import capi, synth
-W, H, B, CAP = 640, 480, 64, 4096
+W, H, B, CAP = 640, 480, int(os.environ.get("SA_BENCH_BATCH", "64")), 4096
 ex = capi.Extractor(capi.orb_params(nfeatures=2000), W, H, max_batch=B, max_keypoints=CAP)
 d_img = torch.from_numpy(np.stack(synth.frame_sequence(W, H, B, seed=1))).cuda()
 kp = torch.zeros(B * CAP * 28, dtype=torch.uint8, device="cuda"); desc = torch.zeros(B * CAP * 32, dtype=torch.uint8, device="cuda")
