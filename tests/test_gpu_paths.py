@@ -163,6 +163,23 @@ def test_extract_other_parameters(oracle, capi):
         assert kp.tobytes() == kp_o.tobytes() and np.array_equal(d, d_o), kw
 
 
+def test_extract_fast_threshold_sweep(oracle, capi):
+    """Every remainder of the threshold in the packed pre-test's rounding ((t + 1) / 4), both ends of its range, and
+    images on which nearly every pixel is a candidate (threshold 0 on noise: the candidate list overflows and is
+    rebuilt with one entry per pixel) or none is."""
+    rng = np.random.default_rng(77)
+    noise = rng.integers(0, 256, (150, 200), dtype=np.uint8)
+    scene = synth.scene(200, 150, 44)
+    for img in (noise, scene):
+        for t in (0, 1, 2, 3, 4, 6, 19, 50, 127, 254, 255):
+            kw = dict(nfeatures=300, fast_threshold=t)
+            ex = capi.Extractor(capi.orb_params(**kw), 200, 150, max_batch=1, max_keypoints=4096)
+            kp, d = ex.extract(img)
+            ex.close()
+            kp_o, d_o = oracle.detect_and_compute(oracle.params(**kw), img)
+            assert kp.tobytes() == kp_o.tobytes() and np.array_equal(d, d_o), t
+
+
 def test_extract_chessboard_golden(oracle, capi):
     """The reference's own image asset: many equal scores, so ties at the cut are exercised."""
     sys.path.insert(0, os.path.join(HERE, "golden"))
