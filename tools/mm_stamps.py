@@ -30,7 +30,7 @@ for it in range(6):     # like the benchmark step: extraction, then the chained 
     ex.extract_batch_async(d_img, B, H * W, W, kp.data_ptr(), desc.data_ptr(), cnt.data_ptr(), CAP, st)
     m.frame_match_chain_async(B, desc.data_ptr() + last * CAP * 32, kp.data_ptr() + last * CAP * KP,
                               cnt.data_ptr() + 4 * last, desc.data_ptr(), kp.data_ptr(), CAP, cnt.data_ptr(),
-                              out, nout, max_dist=300.0, area=-1.0, max_level=-1, stream=st)
+                              out, nout, max_dist=300.0, area=float(os.environ.get("SA_STAMP_AREA", "-1")), max_level=int(os.environ.get("SA_STAMP_LEVEL", "-1")), stream=st)
 torch.cuda.synchronize()
 n = 2048
 buf = np.zeros((n, 10), np.uint64)
