@@ -775,7 +775,7 @@ struct slam_amd_matcher {
                                        // allocated, the finalize kernel puts back what it reads, and a call that fails
                                        // in between enqueues the fill itself before it returns
     unsigned char* static_scratch = nullptr;  // this device's copy of the file-scope scratch array (no-alloc entry point)
-    int window_mode = 0;               // 0: choose by size, 1: always the full sweep, 2: always cell-sorted
+    int window_mode = 0;               // 0: choose by size, 1: always the full sweep, 2: cell-sorted sets and the popcount kernel, 3: cell-sorted sets and the matrix cores
     int sweep_kernel = 0;              // full sweep: 0 = matrix-core kernel (gates and ratio option included), 1 = VALU popcount kernel
     float ratio = 0.f;                 // options beyond the reference, both off by default
     int histo_length = 0;
@@ -858,7 +858,7 @@ static int grow_scratch(slam_amd_matcher* m, DevBuf& b, size_t bytes, bool captu
 }
 
 // Byte layout of the cell-sorted copies of both sets (set 0 = queries, 1 = train): per row
-// descriptors (32 B), position (8 B), index word (4 B); a box (16 B) per 64 rows.
+// descriptors (32 B), position (8 B), index word (4 B); a box (16 B) per 32 rows (one per 64 is used by the popcount kernel).
 struct SortedLayout {
     int scap[2];
     size_t o_desc[2], o_xy[2], o_idx[2], o_box[2], total;
@@ -873,7 +873,7 @@ static SortedLayout sorted_layout(int batch, int nq, int n2) {
         L.o_desc[s] = off; off += r * 32;
         L.o_xy[s] = off; off += r * 8;
         L.o_idx[s] = off; off += r * 4;
-        L.o_box[s] = off; off += (r / 64) * 16;
+        L.o_box[s] = off; off += (r / 32) * 16;
         off = (off + 255) & ~(size_t)255;
     }
     L.total = off;
@@ -894,7 +894,7 @@ extern "C" int slam_amd_matcher_reserve(slam_amd_matcher* m, int batch, int quer
 }
 
 extern "C" int slam_amd_matcher_debug_set_window_mode(slam_amd_matcher* m, int mode) {
-    if (!m || mode < 0 || mode > 2) SA_FAIL(SLAM_AMD_ERR_ARG, "mode must be 0, 1 or 2");
+    if (!m || mode < 0 || mode > 3) SA_FAIL(SLAM_AMD_ERR_ARG, "mode must be 0, 1, 2 or 3");
     m->window_mode = mode;
     return SLAM_AMD_OK;
 }
@@ -944,16 +944,20 @@ static int match_common(slam_amd_matcher* m, int batch,
     const bool second = m->ratio > 0.f;
     if (m->histo_length > 0 && nq > 0 && n2 > 0 && (!k1 || !k2))
         SA_FAIL(SLAM_AMD_ERR_ARG, "the rotation-consistency option needs the keypoints of both sets");
-    // With the window gate on and sets large enough to repay the reordering (from about 10^9 pairs: below that
-    // the full sweep on the matrix cores, which skips blocks of rows a window away, is faster), both sets are
-    // sorted by grid cell and only nearby tiles are compared; same result.
-    bool windowed = area > 0.f && area <= 3.0e38f && nq > 0 && n2 > 0;
-    if (m->window_mode == 1 || no_alloc || chain) windowed = false;   // the full sweep needs no reordered copies
-    else if (m->window_mode == 0) windowed = windowed && (long long)nq * n2 >= (1LL << 30);
     // full sweep: distances on the matrix cores (gates and second-best keys included)
     const bool use_mfma = m->sweep_kernel == 0;
+    // With the window gate on, both sets are first reordered by grid cell (copies in the matcher's scratch), so
+    // that rows that are close in the arrays are close in the image; same result either way.  Train sets that
+    // fit the matrix-core kernel's index field then go through that kernel, which skips the blocks of train rows
+    // a window away from a wave's queries -- most of them, once the sets are ordered; larger ones go to the
+    // popcount kernel over nearby tiles once there are enough pairs to repay the reordering (about 10^9).
+    const bool can_sort = area > 0.f && area <= 3.0e38f && nq > 0 && n2 > 0 && !no_alloc && m->window_mode != 1;
+    bool sorted_mfma = can_sort && use_mfma && n2 <= window_mfma_max_train() && m->window_mode != 2;
+    bool windowed = can_sort && !chain && !sorted_mfma;
+    if (windowed && m->window_mode == 0) windowed = (long long)nq * n2 >= (1LL << 30);
     MatchPlan plan = use_mfma ? plan_match_mfma(batch, nq, n2, m->n_cu, second) : plan_match(batch, nq, n2, m->n_cu, second);
     if (windowed) plan.splits = window_splits(batch, nq, n2, m->n_cu);
+    if (sorted_mfma) plan.splits = window_mfma_splits(batch, nq, n2, m->n_cu);
     int rc;
     const bool capturing = !no_alloc && stream_capturing(st);
     unsigned* best_p;
@@ -998,7 +1002,9 @@ static int match_common(slam_amd_matcher* m, int batch,
         SA_HIP(hipMemsetAsync(second ? static_cast<void*>(part_p) : static_cast<void*>(best_p), 0xff, bytes, st));
     }
     const int dmax = dmax_of(max_dist);
-    if (windowed) {
+    MatchArgs a;
+    memset(&a, 0, sizeof a);
+    if (windowed || sorted_mfma) {
         SpatialSortArgs sa_;
         memset(&sa_, 0, sizeof sa_);
         sa_.qdesc = d1; sa_.qkp = k1; sa_.d_n1 = d_n1; sa_.n1 = n1; sa_.cap1 = cap1;
@@ -1019,6 +1025,9 @@ static int match_common(slam_amd_matcher* m, int batch,
             sa_.tile_box[s] = reinterpret_cast<float4*>(basep + o_box[s]);
             w.sdesc[s] = sa_.sdesc[s]; w.sxy[s] = sa_.sxy[s]; w.sidx[s] = sa_.sidx[s]; w.scap[s] = sa_.scap[s];
         }
+        sa_.batch_q = chain ? 1 : batch;
+        sa_.box_rows = sorted_mfma ? 32 : 64;
+        { ProfScope ps(kStageSpatialSort, st); if ((rc = launch_spatial_sort(sa_, batch, nq, n2, st))) return rc; }
         w.tile_box = sa_.tile_box[1];
         w.d_n1 = d_n1; w.n1 = n1; w.d_n2 = d_n2; w.n2 = n2; w.has_ids = ids != nullptr; w.n_ids = n_ids;
         w.cap1 = cap1; w.area = area; w.max_level = max_level; w.batch = batch;
@@ -1026,11 +1035,10 @@ static int match_common(slam_amd_matcher* m, int batch,
         w.part = second ? part_p : nullptr;
         w.part_pitch = rows;
         w.splits = plan.splits;
-        { ProfScope ps(kStageSpatialSort, st); if ((rc = launch_spatial_sort(sa_, batch, nq, n2, st))) return rc; }
-        { ProfScope ps(kStageMatchWindow, st); if ((rc = launch_match_window(w, batch, nq, st))) return rc; }
+        w.chain = chain ? 1 : 0;
+        ProfScope ps(kStageMatchWindow, st);
+        if ((rc = sorted_mfma ? launch_match_window_mfma(w, batch, nq, st) : launch_match_window(w, batch, nq, st))) return rc;
     } else {
-        MatchArgs a;
-        memset(&a, 0, sizeof a);
         a.qdesc = d1; a.qkp = k1; a.d_n1 = d_n1; a.n1 = n1;
         a.tdesc = d2; a.tkp = k2; a.d_n2 = d_n2; a.n2 = n2;
         a.ids = ids; a.n_ids = n_ids; a.q_xy = q_xy; a.cap1 = cap1; a.cap2 = cap2;

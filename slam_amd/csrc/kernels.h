@@ -155,9 +155,11 @@ struct SpatialSortArgs {
     uint4* sdesc[2];          // [batch][scap][2]  descriptors in cell order
     float2* sxy[2];           // [batch][scap]     positions
     uint32_t* sidx[2];        // [batch][scap]     original index | (octave > max_level) << 31
-    float4* tile_box[2];      // [batch][scap/64]  xmin, xmax, ymin, ymax of every 64-row tile (set 1 only)
+    float4* tile_box[2];      // [batch][scap/box_rows]  xmin, xmax, ymin, ymax of every tile of box_rows rows (set 1 only)
     int scap[2];              // rows per problem in the sorted arrays, multiples of 64
     int qchunks;              // 4096-row chunks of the query set (set by the launcher)
+    int batch_q;              // problems of the query set (the launcher's batch unless set: chained batches reorder one frame)
+    int box_rows;             // rows per box of set 1: 64 (popcount kernel) or 32 (matrix-core kernel)
 };
 
 struct WindowMatchArgs {
@@ -177,6 +179,7 @@ struct WindowMatchArgs {
     unsigned* best;           // [batch][cap1], merged with atomicMin
     uint2* part;              // [splits][part_pitch] (best, second) when the ratio test is on, else null
     size_t part_pitch;
+    int chain;                // matrix-core kernel only: 1 = the queries of problem p are set 1 of problem p - 1 (set 0 for p = 0)
 };
 
 struct FinalizeArgs {
@@ -264,6 +267,9 @@ int launch_match_pairs_mfma(MatchArgs a, int n_pairs, hipStream_t st);
 int launch_spatial_sort(SpatialSortArgs a, int batch, int nq_bound, int nt_bound, hipStream_t st);
 int window_splits(int batch, int nq_bound, int nt_bound, int n_cu);
 int launch_match_window(const WindowMatchArgs& a, int batch, int nq_bound, hipStream_t st);
+int window_mfma_max_train();      // largest train set of the kernel below
+int window_mfma_splits(int batch, int nq_bound, int nt_bound, int n_cu);
+int launch_match_window_mfma(const WindowMatchArgs& a, int batch, int nq_bound, hipStream_t st);   // boxes per 32 train rows
 int launch_finalize(const FinalizeArgs& a, int batch, hipStream_t st);
 int launch_project(const ProjectArgs& a, hipStream_t st);
 int launch_frontend(const FrontendArgs& a, int batch, hipStream_t st);

@@ -248,13 +248,8 @@ __global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : SA_MM_UNGATED_WGS) 
         const int qc = min(qi, nq_bound - 1);
         const size_t row = qs.base + (size_t)((!PAIRS && a.ids) ? a.ids[qc] : qc);
         // 16 bytes of the row per lane half (dwords 4 h .. 4 h + 3); the two dwords the other half needs are swapped below
-#ifdef SA_MM_QOLD
-#pragma unroll
-        for (int s = 0; s < kMmSteps; s++) qw[b][s] = reinterpret_cast<const unsigned*>(qs.desc + row * 32)[2 * s + h];
-#else
         const uint4 own = *reinterpret_cast<const uint4*>(qs.desc + row * 32 + 16 * h);
         qw[b][0] = own.x; qw[b][1] = own.y; qw[b][2] = own.z; qw[b][3] = own.w;
-#endif
         qx[b] = qy[b] = 0.f;
         qoct[b] = 0;
         if (AREA) {
@@ -281,7 +276,6 @@ __global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : SA_MM_UNGATED_WGS) 
 
     // product s takes dword 2 s + h: half 0 holds dwords 0 .. 3 and needs 0, 2 (its own) and 4, 6 (the other half's
     // first and third); half 1 holds 4 .. 7 and needs 1, 3 (the other half's second and fourth) and 5, 7 (its own)
-#ifndef SA_MM_QOLD
 #pragma unroll
     for (int b = 0; b < kMmNB; b++) {
         const unsigned give0 = h ? qw[b][0] : qw[b][1], give1 = h ? qw[b][2] : qw[b][3];
@@ -292,7 +286,6 @@ __global__ __launch_bounds__(kMmBlock, (AREA || LEVEL) ? 2 : SA_MM_UNGATED_WGS) 
         qw[b][2] = h ? o1 : take0;
         qw[b][3] = h ? o3 : take1;
     }
-#endif
     // ---- queries of this wave: expanded once ----
     v4i bq[kMmNB][kMmSteps];
     int pq[kMmNB];      // popcount of the whole query descriptor
@@ -656,6 +649,313 @@ extern "C" int slam_amd_debug_mm_stamps(unsigned long long* out, int n_waves) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mm_stamps), (size_t)n_waves * 10 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// =============================================================================
+// Window-gated matching of sets reordered by grid cell, wave by wave.
+//
+// With the window gate on, a query can only match train rows within `area` of it.  spatial_sort_kernel has put both
+// sets in grid-cell order, so that 64 consecutive queries and 32 consecutive train rows each cover a small patch of
+// the image, and has left the bounding box of every block of 32 train rows.  A wave takes 64 queries (two blocks of
+// 32, expanded once into registers) and first tests every train block's box against its own: the blocks that lie a
+// window or more away -- most of them -- are never fetched.  The others it fetches, expands into its own slice of
+// LDS and multiplies exactly as match_mfma_kernel does (same operands, same accumulator encoding, the same gates on
+// the accumulators); no barrier, no work shared with the other waves of the workgroup, so a wave's time follows
+// its own list of blocks and not the longest list among its neighbours.
+//
+// A row's place in the reordered set says nothing about which row it was, and ties must go to the lowest original
+// train index: the accumulator operand of a block's first product carries the row's original index (13 bits: the 5
+// bits that hold the row inside its block in match_mfma_kernel plus the 8 fraction bits that a float in
+// [2^15, 2^16) has left), so the bit patterns order like (distance, original index) across all blocks and the
+// running minimum is a plain unsigned minimum.  Train sets of up to 2^13 rows.
+// =============================================================================
+constexpr int kWmWaves = 4;
+constexpr int kWmIdxBits = 13;
+constexpr int kWmMaxTrain = 1 << kWmIdxBits;
+constexpr int kWmGroups = kWmMaxTrain / kMmSub / 64;      // 64-bit masks of live blocks per wave
+
+template <bool LEVEL, bool SECOND>
+__global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(WindowMatchArgs a) {
+    __shared__ uint4 s_rows[kWmWaves][2][kMmSubU4];                       // a block's expanded rows, two deep per wave
+    __shared__ __align__(16) float s_pos[kWmWaves][2][3][kMmSub];         // its rows' x, y and accumulator operand
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // problem fastest, then the split of the train blocks, then the group of four query tiles
+    const int prob = blockIdx.x % a.batch;
+    const int rest = blockIdx.x / a.batch;
+    const int split = rest % a.splits;
+    const int qtile = (rest / a.splits) * kWmWaves + wave;
+
+    // the query side: the problem's own rows of set 0, or, in a chained batch, the frame before (set 0 holds the one
+    // before the batch)
+    int qset = 0, qprob = prob, nqb = a.n1;
+    const int32_t* qcount = a.d_n1 ? a.d_n1 + prob : nullptr;
+    if (a.chain) {
+        if (prob == 0) { qcount = a.d_n1; }
+        else { qset = 1; qprob = prob - 1; nqb = a.n2; qcount = a.d_n2 ? a.d_n2 + (prob - 1) : nullptr; }
+    }
+    int n1 = nqb, nt = a.n2;
+    if (qcount) n1 = min(n1, *qcount);
+    if (a.d_n2) nt = min(nt, a.d_n2[prob]);
+    const int nq = a.has_ids ? a.n_ids : n1;
+    if (qtile * 64 >= nq || nt <= 0) return;      // (no workgroup barrier below: the waves are on their own)
+
+    const uint4* const qd = a.sdesc[qset] + (size_t)qprob * a.scap[qset] * 2;
+    const float2* const qxy = a.sxy[qset] + (size_t)qprob * a.scap[qset];
+    const uint32_t* const qidx = a.sidx[qset] + (size_t)qprob * a.scap[qset];
+    const uint4* const td = a.sdesc[1] + (size_t)prob * a.scap[1] * 2;
+    const unsigned* const txy = reinterpret_cast<const unsigned*>(a.sxy[1] + (size_t)prob * a.scap[1]);
+    const uint32_t* const tidx = a.sidx[1] + (size_t)prob * a.scap[1];
+    const float4* const tbox = a.tile_box + (size_t)prob * (a.scap[1] / kMmSub);
+
+    // ---- this wave's queries: both lane halves hold the same 32 per block, half h the dwords 2s + h of product s ----
+    v4i bq[kMmNB][kMmSteps];
+    int pq[kMmNB];
+    float qx[kMmNB], qy[kMmNB];
+    unsigned qword[kMmNB];
+    bool qvalid[kMmNB], qhigh[kMmNB];
+    bool any_qhigh = false;
+    const float inf = __uint_as_float(0x7f800000u);
+    float qbox[4] = {inf, -inf, inf, -inf};      // x min, x max, y min, y max of the queries with finite positions
+#pragma unroll
+    for (int b = 0; b < kMmNB; b++) {
+        const int qi = qtile * 64 + b * 32 + r;
+        qvalid[b] = qi < nq;
+        const int qc = min(qi, nq - 1);
+        const uint4 own = qd[2 * qc + h];
+        const float2 p = qxy[qc];
+        qword[b] = qidx[qc];
+        // 16 bytes of the row per lane half (dwords 4 h .. 4 h + 3); product s takes dword 2 s + h, so either half
+        // hands two of its dwords to the other
+        const unsigned give0 = h ? own.x : own.y, give1 = h ? own.z : own.w;
+        const unsigned take0 = (unsigned)__shfl_xor((int)give0, 32, 64), take1 = (unsigned)__shfl_xor((int)give1, 32, 64);
+        const unsigned qw[kMmSteps] = {h ? take0 : own.x, h ? take1 : own.z, h ? own.y : take0, h ? own.w : take1};
+        int pc = 0;
+#pragma unroll
+        for (int s = 0; s < kMmSteps; s++) {
+            pc += __builtin_popcount(qw[s]);
+            bq[b][s] = expand_query(qw[s]);
+        }
+        pq[b] = pc + __shfl_xor(pc, 32, 64);
+        qhigh[b] = LEVEL && qvalid[b] && (qword[b] >> 31) != 0u;
+        qword[b] &= 0x7fffffffu;
+        any_qhigh = any_qhigh || (LEVEL && __ballot(qhigh[b]) != 0ull);
+        qx[b] = p.x; qy[b] = p.y;
+        const bool odd = (__float_as_uint(p.x) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(p.y) & 0x7f800000u) == 0x7f800000u;
+        if (odd) {
+            // a position that is NaN or infinite fails the window with every train row: -infinity here, +infinity on the
+            // train side, so that no difference is ever a NaN (the window test takes a maximum, which would drop one)
+            if ((__float_as_uint(p.x) & 0x7f800000u) == 0x7f800000u) qx[b] = -inf;
+            if ((__float_as_uint(p.y) & 0x7f800000u) == 0x7f800000u) qy[b] = -inf;
+        } else if (qvalid[b]) {
+            qbox[0] = fminf(qbox[0], p.x); qbox[1] = fmaxf(qbox[1], p.x);
+            qbox[2] = fminf(qbox[2], p.y); qbox[3] = fmaxf(qbox[3], p.y);
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        qbox[0] = fminf(qbox[0], __shfl_xor(qbox[0], d, 64)); qbox[1] = fmaxf(qbox[1], __shfl_xor(qbox[1], d, 64));
+        qbox[2] = fminf(qbox[2], __shfl_xor(qbox[2], d, 64)); qbox[3] = fmaxf(qbox[3], __shfl_xor(qbox[3], d, 64));
+    }
+
+    // ---- the train blocks this wave has to look at: lane l tests block 64 g + l.  fl(a - b) is monotone in a and in
+    //      b, so when the nearest edges of the two boxes are a window apart, every pair of their points is ----
+    const int nblocks = (nt + kMmSub - 1) / kMmSub;
+    unsigned long long live[kWmGroups];
+#pragma unroll
+    for (int g = 0; g < kWmGroups; g++) {
+        const int blk = g * 64 + lane;
+        bool on = blk < nblocks && (blk % a.splits) == split;
+        if (on) {
+            const float4 bb = tbox[blk];      // x min, x max, y min, y max
+            on = !(bb.x - qbox[1] >= a.area || qbox[0] - bb.y >= a.area || bb.z - qbox[3] >= a.area || qbox[2] - bb.w >= a.area);
+        }
+        live[g] = __ballot(on);
+    }
+    // the next block of the list (-1: none); the masks are the same in every lane
+    auto next_block = [&]() {
+#pragma unroll
+        for (int g = 0; g < kWmGroups; g++) {
+            if (live[g] != 0ull) {
+                const int j = __builtin_ctzll(live[g]);
+                live[g] &= live[g] - 1ull;
+                return g * 64 + j;
+            }
+        }
+        return -1;
+    };
+
+    struct Fetched { uint4 rows; unsigned pos, word; };
+    // lane (r, h): dwords 4 h .. 4 h + 3 of the block's row r, its x (h = 0) or y, its index word; rows past the end of
+    // the set repeat the last one and are marked as failed below
+    auto fetch = [&](int blk, Fetched& f) {
+        const unsigned t = min((unsigned)(blk * kMmSub + r), (unsigned)(nt - 1));
+        f.rows = td[2 * t + h];
+        f.pos = txy[2 * t + h];
+        f.word = tidx[t];
+    };
+    // into LDS slice p: expanded rows as [step][half][row] of 16 bytes (dword d belongs to step d / 2, half d % 2),
+    // positions, accumulator operands 2^15 + 32 * 256 + index / 256 (exact in a float); returns the mask of rows
+    // above max_level
+    auto stage = [&](int p, const Fetched& f) {
+        uint4* const dst = s_rows[wave][p];
+        dst[(4 * h) * 32 + r] = expand_train(f.rows.x);
+        dst[(4 * h + 1) * 32 + r] = expand_train(f.rows.y);
+        dst[(4 * h + 2) * 32 + r] = expand_train(f.rows.z);
+        dst[(4 * h + 3) * 32 + r] = expand_train(f.rows.w);
+        const bool odd = (f.pos & 0x7f800000u) == 0x7f800000u;
+        s_pos[wave][p][h][r] = __uint_as_float(odd ? 0x7f800000u : f.pos);
+        if (h == 0) s_pos[wave][p][2][r] = (float)kMmBias + (float)(f.word & (unsigned)(kWmMaxTrain - 1)) * (1.f / 256.f);
+        return LEVEL ? (unsigned)__ballot((f.word >> 31) != 0u) : 0u;
+    };
+
+    int scale_a = kMmScaleOne, scale_b = kMmScale64;
+    asm volatile("" : "+v"(scale_a), "+v"(scale_b));
+    const int area_bits_m1 = (int)__float_as_uint(a.area) - 1;
+    unsigned best[kMmNB], second[kMmNB];
+#pragma unroll
+    for (int b = 0; b < kMmNB; b++) best[b] = second[b] = kMmNoMatch;
+    // pattern -> key Hb << 20 | original index (a pattern with the failure mark: Hb = 1023)
+    auto bits_key = [](unsigned bits) {
+        const unsigned u = min(bits - kMmBinade, 0x7fffffu);
+        return ((u & ~0x1fffu) << 7) + (u & 0x1fffu);
+    };
+
+    Fetched f;
+    int blk = next_block();
+    if (blk >= 0) fetch(blk, f);
+    int p = 0;
+    while (blk >= 0) {
+        const unsigned high = stage(p, f);
+        const int rows_left = nt - blk * kMmSub;
+        blk = next_block();
+        if (blk >= 0) fetch(blk, f);       // in flight while this block is worked on
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        v16f acc[kMmNB];
+        {
+            v16f cin;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const v4f v = *reinterpret_cast<const v4f*>(&s_pos[wave][p][2][8 * j + 4 * h]);
+                cin[4 * j] = v.x; cin[4 * j + 1] = v.y; cin[4 * j + 2] = v.z; cin[4 * j + 3] = v.w;
+            }
+#pragma unroll
+            for (int s = 0; s < kMmSteps; s++) {
+                const v4i af = *reinterpret_cast<const v4i*>(&s_rows[wave][p][s * 64 + h * 32 + r]);
+#pragma unroll
+                for (int b = 0; b < kMmNB; b++) acc[b] = product(af, bq[b][s], s == 0 ? cin : acc[b], scale_a, scale_b);
+            }
+        }
+        // ---- gates, as in match_mfma_kernel: the sign of (bits(area) - 1) - bits(max(|dx|, |dy|)) is "not inside
+        //      the window"; bit `row` of the block's mask of high rows for queries that are high themselves; rows past
+        //      the end of the set ----
+        auto gates = [&](auto level_on) {
+            constexpr bool kLevelOn = LEVEL && decltype(level_on)::value;
+            unsigned mine[kMmNB];
+#pragma unroll
+            for (int b = 0; b < kMmNB; b++) mine[b] = (kLevelOn && qhigh[b]) ? high >> (4 * h) : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const v4f x4 = *reinterpret_cast<const v4f*>(&s_pos[wave][p][0][8 * j + 4 * h]);
+                const v4f y4 = *reinterpret_cast<const v4f*>(&s_pos[wave][p][1][8 * j + 4 * h]);
+#pragma unroll
+                for (int b = 0; b < kMmNB; b++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int i = 4 * j + c;
+                        const float dx = qx[b] - x4[c], dy = qy[b] - y4[c];
+                        unsigned sign = (unsigned)(area_bits_m1 - (int)__float_as_uint(fmaxf(fabsf(dx), fabsf(dy))));
+                        if (kLevelOn) sign |= mine[b] << (31 - acc_row(i, 0));
+                        const float v = acc[b][i];
+                        acc[b][i] = __uint_as_float((sign & kMmFail) | __float_as_uint(v));
+                    }
+            }
+        };
+        if (LEVEL && high != 0u && any_qhigh) gates(std::true_type());
+        else gates(std::false_type());
+        if (rows_left < kMmSub) {
+#pragma unroll
+            for (int b = 0; b < kMmNB; b++)
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    if (acc_row(i, h) >= rows_left) acc_fail(acc[b], i);
+        }
+        // ---- the block's minimum (two smallest with SECOND) into the running one ----
+#pragma unroll
+        for (int b = 0; b < kMmNB; b++) {
+            if (!SECOND) {
+                unsigned m = best[b];
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) m = min(min(m, acc_bits(acc[b], i)), acc_bits(acc[b], i + 1));
+                best[b] = m;
+            } else {
+                unsigned lo = kMmNoMatch, hi = kMmNoMatch;
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const unsigned x = acc_bits(acc[b], i), y = acc_bits(acc[b], i + 1);
+                    const unsigned l2 = min(x, y), h2 = max(x, y);
+                    hi = min(max(lo, l2), min(hi, h2));
+                    lo = min(lo, l2);
+                }
+                const unsigned klo = bits_key(lo), khi = bits_key(hi);
+                second[b] = min(max(best[b], klo), min(second[b], khi));
+                best[b] = min(best[b], klo);
+            }
+        }
+        p ^= 1;
+    }
+
+#pragma unroll
+    for (int b = 0; b < kMmNB; b++) {
+        const unsigned mine = SECOND ? best[b] : bits_key(best[b]);
+        const unsigned ob = (unsigned)__shfl_xor((int)mine, 32, 64);
+        const unsigned m = min(mine, ob);
+        // pairs that failed a gate and rows beyond the set carry distances above 256
+        auto final_key = [&](unsigned v) -> unsigned {
+            const unsigned d = (v >> kMmIdxBits) + (unsigned)pq[b] - 256u;
+            return d <= 256u ? ((d << kMmIdxBits) | (v & ((1u << kMmIdxBits) - 1u))) : kMmNoMatch;
+        };
+        const size_t out = (size_t)prob * a.cap1 + qword[b];
+        if (SECOND) {
+            const unsigned os = (unsigned)__shfl_xor((int)second[b], 32, 64);
+            const unsigned m2 = min(max(mine, ob), min(second[b], os));
+            if (h == 0 && qvalid[b]) a.part[(size_t)split * a.part_pitch + out] = make_uint2(final_key(m), final_key(m2));
+            continue;
+        }
+        if (h != 0 || !qvalid[b]) continue;
+        const unsigned key = final_key(m);
+        if (key != kMmNoMatch) atomicMin(&a.best[out], key);
+    }
+}
+
+int window_mfma_max_train() { return kWmMaxTrain; }
+
+// Waves of 64 queries are the unit of work; the train blocks are dealt round-robin to `splits` waves per query tile
+// only when the query tiles alone leave SIMDs without a second wave (a split expands its queries again).
+int window_mfma_splits(int batch, int nq_bound, int nt_bound, int n_cu) {
+    const long long qwaves = (long long)div_up(nq_bound, 64) * batch;
+    if (qwaves <= 0) return 1;
+    const long long want = div_up(n_cu * 8, (int)std::min<long long>(qwaves, 1 << 30));
+    return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(want, kMaxSecondSplits), div_up(nt_bound, 4 * kMmSub)));
+}
+
+int launch_match_window_mfma(const WindowMatchArgs& a, int batch, int nq_bound, hipStream_t st) {
+    if (a.n2 > kWmMaxTrain || !(a.area > 0.f) || a.splits < 1)
+        SA_FAIL(SLAM_AMD_ERR_ARG, "match: the reordered matrix-core kernel takes a window and at most 8192 train rows");
+    const long long blocks = (long long)div_up(div_up(nq_bound, 64), kWmWaves) * a.splits * batch;
+    if (blocks <= 0) return SLAM_AMD_OK;
+    if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match: problem too large for one launch");
+    const dim3 grid((unsigned)blocks), block(kWmWaves * 64);
+    const bool level = a.max_level != -1, second = a.part != nullptr;
+    if (level && second) hipLaunchKernelGGL((match_window_mfma_kernel<true, true>), grid, block, 0, st, a);
+    else if (level) hipLaunchKernelGGL((match_window_mfma_kernel<true, false>), grid, block, 0, st, a);
+    else if (second) hipLaunchKernelGGL((match_window_mfma_kernel<false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((match_window_mfma_kernel<false, false>), grid, block, 0, st, a);
+    SA_HIP(hipGetLastError());
+    return SLAM_AMD_OK;
+}
 
 // Workgroups of 256 queries; the train set is split so that the grid fills the chip several
 // times over (capacities bound the grid, the true counts live on the device; workgroups beyond

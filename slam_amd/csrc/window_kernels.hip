@@ -58,9 +58,10 @@ __global__ __launch_bounds__(kSortBlock) void spatial_sort_kernel(SpatialSortArg
     const int chunk = set == 0 ? blockIdx.x : blockIdx.x - a.qchunks;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
+    if (set == 0 && prob >= a.batch_q) return;
     int n1 = a.n1, n2 = a.n2;
-    if (a.d_n1) n1 = min(n1, a.d_n1[prob]);
-    if (a.d_n2) n2 = min(n2, a.d_n2[prob]);
+    if (set == 0 && a.d_n1) n1 = min(n1, a.d_n1[prob]);
+    if (set == 1 && a.d_n2) n2 = min(n2, a.d_n2[prob]);
     const int n = set == 0 ? (a.ids ? a.n_ids : n1) : n2;
     const int c0 = chunk * kChunkRows;
     if (c0 >= n) return;
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(kSortBlock) void spatial_sort_kernel(SpatialSortArg
     uint4* sdesc = a.sdesc[set] + ((size_t)prob * scap + c0) * 2;
     float2* sxy = a.sxy[set] + (size_t)prob * scap + c0;
     uint32_t* sidx = a.sidx[set] + (size_t)prob * scap + c0;
-    float4* box = a.tile_box[set] + (size_t)prob * (scap / 64) + c0 / 64;
+    const int box_rows = a.box_rows;      // 64 or 32
+    float4* box = a.tile_box[set] + (size_t)prob * (scap / box_rows) + c0 / box_rows;
 
     // this thread's rows: position, source row and index word stay in registers
     float2 p[kRowsPerThread];
@@ -172,8 +174,11 @@ __global__ __launch_bounds__(kSortBlock) void spatial_sort_kernel(SpatialSortArg
             const float2 q = sxy[i];
             if (finite2(q.x, q.y)) { bx0 = bx1 = q.x; by0 = by1 = q.y; }
         }
-        bx0 = wave_min(bx0); bx1 = wave_max(bx1); by0 = wave_min(by0); by1 = wave_max(by1);
-        if (lane == 0) box[t] = make_float4(bx0, bx1, by0, by1);
+        for (int o = box_rows >> 1; o > 0; o >>= 1) {
+            bx0 = fminf(bx0, __shfl_xor(bx0, o, 64)); bx1 = fmaxf(bx1, __shfl_xor(bx1, o, 64));
+            by0 = fminf(by0, __shfl_xor(by0, o, 64)); by1 = fmaxf(by1, __shfl_xor(by1, o, 64));
+        }
+        if ((lane & (box_rows - 1)) == 0 && t * 64 + lane < cn) box[(t * 64 + lane) / box_rows] = make_float4(bx0, bx1, by0, by1);
     }
 }
 
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(kWinWaves * 64) void match_window_kernel(WindowMatc
     const uint4* td = a.sdesc[1] + (size_t)prob * a.scap[1] * 2;
     const float2* txy = a.sxy[1] + (size_t)prob * a.scap[1];
     const uint32_t* tidx = a.sidx[1] + (size_t)prob * a.scap[1];
-    const float4* tbox = a.tile_box + (size_t)prob * (a.scap[1] / 64);
+    const float4* tbox = a.tile_box + (size_t)prob * (a.scap[1] / 64);      // (launched with boxes per 64 rows)
 
     const int qi = qtile * 64 + lane;
     const bool qvalid = qi < nq;
@@ -319,6 +324,8 @@ __global__ __launch_bounds__(kWinWaves * 64) void match_window_kernel(WindowMatc
 
 int launch_spatial_sort(SpatialSortArgs a, int batch, int nq_bound, int nt_bound, hipStream_t st) {
     a.qchunks = div_up(nq_bound, kChunkRows);
+    if (a.batch_q <= 0) a.batch_q = batch;
+    if (a.box_rows != 32) a.box_rows = 64;
     const int chunks = a.qchunks + div_up(nt_bound, kChunkRows);
     hipLaunchKernelGGL(spatial_sort_kernel, dim3(chunks, batch), dim3(kSortBlock), 0, st, a);
     SA_HIP(hipGetLastError());

@@ -128,10 +128,45 @@ def test_cell_sorted_window_match_equals_full_sweep(oracle, capi, nq, nt, area, 
     d1, k1, d2, k2 = _sets(nq, nt, 51)
     ref = oracle.match_gated(d1, k1, d2, k2, 300.0, area, max_level)
     m = capi.Matcher()
-    for mode in (2, 1, 0):
+    for mode in (3, 2, 1, 0):
         m.debug_set_window_mode(mode)
         got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=area, max_level=max_level)
         assert np.array_equal(got, ref), mode
+    m.close()
+
+
+@pytest.mark.parametrize("nt", [2030, 8192, 700])
+def test_cell_sorted_matrix_core_match_ties_and_options(oracle, capi, nt):
+    """Reordered sets on the matrix cores: equal train rows at nearby positions (the lowest original index must
+    win wherever the reordering puts the rows), the ratio test and the rotation check, ids and query positions."""
+    nq = 2030
+    d1, k1, d2, k2 = _sets(nq, nt, 91 + nt)
+    rng = np.random.default_rng(nt)
+    # groups of identical train rows scattered over the set, all inside one window
+    for g in range(40):
+        rows = rng.choice(nt, size=5, replace=False)
+        d2[rows] = d2[rows[0]]
+        k2["x"][rows] = k2["x"][rows[0]] + rng.uniform(-20, 20, 5).astype(np.float32)
+        k2["y"][rows] = k2["y"][rows[0]] + rng.uniform(-20, 20, 5).astype(np.float32)
+        q = rng.integers(0, nq)
+        d1[q] = d2[rows[0]]
+        k1["x"][q] = k2["x"][rows[0]]; k1["y"][q] = k2["y"][rows[0]]
+    m = capi.Matcher()
+    m.debug_set_window_mode(3)
+    for area, lvl in ((50.0, 4), (50.0, -1), (8.0, 2), (1e9, 4)):
+        got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=area, max_level=lvl)
+        ref = oracle.match_gated(d1, k1, d2, k2, 300.0, area, lvl)
+        assert np.array_equal(got, ref), (area, lvl)
+    ids = np.sort(rng.permutation(nq)[:1500]).astype(np.int32)
+    qpos = np.stack([k1["x"][ids], k1["y"][ids]], 1).astype(np.float32) + np.float32(3.0)
+    kq = k1[ids].copy(); kq["x"] = qpos[:, 0]; kq["y"] = qpos[:, 1]
+    ref = oracle.match_gated(d1[ids], kq, d2, k2, 300.0, 50.0, 4)
+    ref["queryIdx"] = ids[ref["queryIdx"]]
+    got = m.frame_match(d1, k1, d2, k2, ids=ids, q_xy=qpos, max_dist=300.0, area=50.0, max_level=4)
+    assert np.array_equal(got, ref)
+    m.set_options(0.9, 30)
+    got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=45.0, max_level=4)
+    assert np.array_equal(got, oracle.match_gated_ex(d1, k1, d2, k2, 300.0, 45.0, 4, 0.9, 30))
     m.close()
 
 
@@ -158,15 +193,16 @@ def test_cell_sorted_window_match_odd_positions(oracle, capi):
     for area in (40.0, 1.0e30):
         ref = oracle.match_gated(d1[ids], kq, d2, k2, 300.0, area, 4)
         ref["queryIdx"] = ids[ref["queryIdx"]]
-        for mode in (2, 1):
+        for mode in (3, 2, 1):
             m.debug_set_window_mode(mode)
             got = m.frame_match(d1, k1, d2, k2, ids=ids, q_xy=qpos, max_dist=300.0, area=area, max_level=4)
             assert np.array_equal(got, ref), (area, mode)
     # every position identical
     k1["x"] = k1["y"] = 7.0; k2["x"] = k2["y"] = 7.25
-    m.debug_set_window_mode(2)
-    got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=0.5, max_level=-1)
-    assert np.array_equal(got, oracle.match_gated(d1, k1, d2, k2, 300.0, 0.5, -1)) and len(got) == nq
+    for mode in (3, 2):
+        m.debug_set_window_mode(mode)
+        got = m.frame_match(d1, k1, d2, k2, max_dist=300.0, area=0.5, max_level=-1)
+        assert np.array_equal(got, oracle.match_gated(d1, k1, d2, k2, 300.0, 0.5, -1)) and len(got) == nq
     # the options ride on the cell-sorted path as well
     d1, k1, d2, k2 = _sets(nq, nt, 62)
     m.set_options(0.9, 30)

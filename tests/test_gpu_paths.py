@@ -293,7 +293,8 @@ def test_frame_match_chain(oracle, capi):
     for ratio, histo in ((0.0, 0), (0.9, 30)):
         m.set_options(ratio, histo)
         m.reserve(B, CAP, CAP)
-        for area, lvl in ((-1.0, -1), (80.0, 4), (25.0, -1)):
+        for area, lvl, mode in ((-1.0, -1, 0), (80.0, 4, 3), (25.0, -1, 3), (80.0, 4, 1), (25.0, -1, 1)):
+            m.debug_set_window_mode(mode)       # 3: both sets reordered by grid cell, 1: as they are
             m.frame_match_chain_async(B, Dp, Kp, Np, D, K, CAP, N, out, nout, 300.0, area, lvl, st)
             torch.cuda.synchronize()
             res = out.cpu().numpy().view(capi.DMATCH_DTYPE)
@@ -323,7 +324,7 @@ def test_frame_match_async_and_batch(oracle, capi):
     N1 = torch.tensor(n1, dtype=torch.int32, device="cuda"); N2 = torch.tensor(n2, dtype=torch.int32, device="cuda")
     out = torch.zeros(B * CAP * DM, dtype=torch.uint8, device="cuda")
     nout = torch.zeros(B, dtype=torch.int32, device="cuda")
-    for area, lvl, mode in ((-1.0, -1, 0), (80.0, 4, 1), (80.0, 4, 2), (25.0, -1, 2)):
+    for area, lvl, mode in ((-1.0, -1, 0), (80.0, 4, 1), (80.0, 4, 2), (25.0, -1, 2), (80.0, 4, 3), (25.0, -1, 3), (80.0, 4, 0)):
         m.debug_set_window_mode(mode)
         m.frame_match_batch_async(B, D1, K1, CAP, N1, D2, K2, CAP, N2, out, nout, 300.0, area, lvl, st)
         torch.cuda.synchronize()

@@ -58,12 +58,13 @@ m = capi.Matcher()
 m.debug_set_sweep_kernel(kernel)
 m.reserve(B, CAP, CAP)
 last = B - 1
-for area, lvl in ((-1.0, -1), (-1.0, 4), (-1.0, 3), (50.0, 4), (50.0, -1)):
+for area, lvl, mode in ((-1.0, -1, 0), (-1.0, 4, 0), (-1.0, 3, 0), (50.0, 4, 1), (50.0, 4, 3), (50.0, -1, 1), (50.0, -1, 3)):
+    m.debug_set_window_mode(mode)      # 1: the sets as they are, 3: reordered by grid cell first
     def chain():
         m.frame_match_chain_async(B, desc.data_ptr() + last * CAP * 32, kp.data_ptr() + last * CAP * KP,
                                   cnt.data_ptr() + 4 * last, desc.data_ptr(), kp.data_ptr(), CAP, cnt.data_ptr(),
                                   out, nout, max_dist=300.0, area=area, max_level=lvl, stream=st)
-    timed("%d frames chained  area=%g max_level=%d" % (B, area, lvl), chain, cmp_frames)
+    timed("%d frames chained  area=%g max_level=%d%s" % (B, area, lvl, " reordered" if mode == 3 else ""), chain, cmp_frames)
     print("    matches per frame: %.1f" % float(nout.cpu().numpy().mean()))
 mr = capi.Matcher()
 mr.debug_set_sweep_kernel(kernel)
@@ -75,6 +76,7 @@ for area, lvl in ((-1.0, -1), (-1.0, 4)):
                                    cnt.data_ptr() + 4 * last, desc.data_ptr(), kp.data_ptr(), CAP, cnt.data_ptr(),
                                    out, nout, max_dist=300.0, area=area, max_level=lvl, stream=st)
     timed("%d frames chained ratio 0.8  area=%g lvl=%d" % (B, area, lvl), chain_r, cmp_frames)
+m.debug_set_window_mode(0)
 ex.close(); mr.close()
 if only_frames:
     m.close()
@@ -96,11 +98,11 @@ for nq, nt, w, h in ((20000, 4000, 1241, 376), (10000, 10000, 3840, 2160)):
     o = torch.zeros(nq * DM, dtype=torch.uint8, device=dev)
     n = torch.zeros(1, dtype=torch.int32, device=dev)
     m.reserve(1, nq, nt)
-    for area, lvl, mode in ((-1.0, -1, 1), (-1.0, 4, 1), (50.0, 4, 1), (50.0, 4, 2)):
+    for area, lvl, mode in ((-1.0, -1, 1), (-1.0, 4, 1), (50.0, 4, 1), (50.0, 4, 2), (50.0, 4, 3)):
         m.debug_set_window_mode(mode)
         def one():
             m.frame_match_async(D1, K1, nq, None, D2, K2, nt, None, o, n, max_dist=300.0, area=area, max_level=lvl, stream=st)
-        timed("%d x %d area=%g lvl=%d %s" % (nq, nt, area, lvl, "cell-sorted" if mode == 2 else "full sweep"), one, float(nq) * nt)
+        timed("%d x %d area=%g lvl=%d %s" % (nq, nt, area, lvl, {1: "full sweep", 2: "cell-sorted, popcount", 3: "cell-sorted, matrix cores"}[mode]), one, float(nq) * nt)
 m.debug_set_window_mode(0)
 
 # ---- keyframe pairs ----
