@@ -1027,6 +1027,7 @@ static int match_common(slam_amd_matcher* m, int batch,
         }
         sa_.batch_q = chain ? 1 : batch;
         sa_.box_rows = sorted_mfma ? 32 : 64;
+        sa_.copy_desc = sorted_mfma ? 0 : 1;
         { ProfScope ps(kStageSpatialSort, st); if ((rc = launch_spatial_sort(sa_, batch, nq, n2, st))) return rc; }
         w.tile_box = sa_.tile_box[1];
         w.d_n1 = d_n1; w.n1 = n1; w.d_n2 = d_n2; w.n2 = n2; w.has_ids = ids != nullptr; w.n_ids = n_ids;
@@ -1036,6 +1037,7 @@ static int match_common(slam_amd_matcher* m, int batch,
         w.part_pitch = rows;
         w.splits = plan.splits;
         w.chain = chain ? 1 : 0;
+        w.qdesc = d1; w.tdesc = d2; w.ids = ids; w.cap2 = cap2;
         ProfScope ps(kStageMatchWindow, st);
         if ((rc = sorted_mfma ? launch_match_window_mfma(w, batch, nq, st) : launch_match_window(w, batch, nq, st))) return rc;
     } else {

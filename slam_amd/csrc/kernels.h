@@ -160,6 +160,7 @@ struct SpatialSortArgs {
     int qchunks;              // 4096-row chunks of the query set (set by the launcher)
     int batch_q;              // problems of the query set (the launcher's batch unless set: chained batches reorder one frame)
     int box_rows;             // rows per box of set 1: 64 (popcount kernel) or 32 (matrix-core kernel)
+    int copy_desc;            // 1: the descriptors are copied into sdesc (popcount kernel); 0: the matcher fetches them by index
 };
 
 struct WindowMatchArgs {
@@ -179,7 +180,12 @@ struct WindowMatchArgs {
     unsigned* best;           // [batch][cap1], merged with atomicMin
     uint2* part;              // [splits][part_pitch] (best, second) when the ratio test is on, else null
     size_t part_pitch;
-    int chain;                // matrix-core kernel only: 1 = the queries of problem p are set 1 of problem p - 1 (set 0 for p = 0)
+    // matrix-core kernel only
+    int chain;                // 1 = the queries of problem p are set 1 of problem p - 1 (set 0 for p = 0)
+    const uint8_t* qdesc;     // the descriptors where the caller holds them, fetched through the index words (sdesc is not read)
+    const uint8_t* tdesc;
+    const int32_t* ids;       // the caller's gather of set-1 rows, or null
+    int cap2;                 // rows between consecutive problems in tdesc (cap1: in qdesc)
 };
 
 struct FinalizeArgs {

@@ -673,10 +673,21 @@ constexpr int kWmIdxBits = 13;
 constexpr int kWmMaxTrain = 1 << kWmIdxBits;
 constexpr int kWmGroups = kWmMaxTrain / kMmSub / 64;      // 64-bit masks of live blocks per wave
 
+#ifdef SA_WM_COUNT
+// Diagnostic build only: waves that ran, train blocks they worked on, train blocks they could have, the longest list.
+__device__ unsigned long long g_wm_count[4];
+extern "C" int slam_amd_debug_wm_count(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wm_count), sizeof g_wm_count) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wm_count), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
 template <bool LEVEL, bool SECOND>
 __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(WindowMatchArgs a) {
     __shared__ uint4 s_rows[kWmWaves][2][kMmSubU4];                       // a block's expanded rows, two deep per wave
     __shared__ __align__(16) float s_pos[kWmWaves][2][3][kMmSub];         // its rows' x, y and accumulator operand
+    __shared__ unsigned short s_list[kWmWaves][kWmMaxTrain / kMmSub];     // the train blocks a wave works on
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     // problem fastest, then the split of the train blocks, then the group of four query tiles
@@ -699,10 +710,12 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
     const int nq = a.has_ids ? a.n_ids : n1;
     if (qtile * 64 >= nq || nt <= 0) return;      // (no workgroup barrier below: the waves are on their own)
 
-    const uint4* const qd = a.sdesc[qset] + (size_t)qprob * a.scap[qset] * 2;
+    // the descriptors stay where the caller holds them and are fetched through the index words
+    const uint4* const qd = reinterpret_cast<const uint4*>(qset == 0 ? a.qdesc : a.tdesc) +
+                            (a.chain ? (size_t)qprob * a.cap2 : (size_t)qprob * a.cap1) * 2;
     const float2* const qxy = a.sxy[qset] + (size_t)qprob * a.scap[qset];
     const uint32_t* const qidx = a.sidx[qset] + (size_t)qprob * a.scap[qset];
-    const uint4* const td = a.sdesc[1] + (size_t)prob * a.scap[1] * 2;
+    const uint4* const td = reinterpret_cast<const uint4*>(a.tdesc) + (size_t)prob * a.cap2 * 2;
     const unsigned* const txy = reinterpret_cast<const unsigned*>(a.sxy[1] + (size_t)prob * a.scap[1]);
     const uint32_t* const tidx = a.sidx[1] + (size_t)prob * a.scap[1];
     const float4* const tbox = a.tile_box + (size_t)prob * (a.scap[1] / kMmSub);
@@ -721,9 +734,11 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
         const int qi = qtile * 64 + b * 32 + r;
         qvalid[b] = qi < nq;
         const int qc = min(qi, nq - 1);
-        const uint4 own = qd[2 * qc + h];
-        const float2 p = qxy[qc];
         qword[b] = qidx[qc];
+        const float2 p = qxy[qc];
+        int qsrc = (int)(qword[b] & 0x7fffffffu);
+        if (a.ids) qsrc = a.ids[qsrc];
+        const uint4 own = qd[2 * qsrc + h];
         // 16 bytes of the row per lane half (dwords 4 h .. 4 h + 3); product s takes dword 2 s + h, so either half
         // hands two of its dwords to the other
         const unsigned give0 = h ? own.x : own.y, give1 = h ? own.z : own.w;
@@ -760,7 +775,7 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
     // ---- the train blocks this wave has to look at: lane l tests block 64 g + l.  fl(a - b) is monotone in a and in
     //      b, so when the nearest edges of the two boxes are a window apart, every pair of their points is ----
     const int nblocks = (nt + kMmSub - 1) / kMmSub;
-    unsigned long long live[kWmGroups];
+    int n_live = 0;      // the list goes through LDS: walking bit masks costs more instructions than the list has entries
 #pragma unroll
     for (int g = 0; g < kWmGroups; g++) {
         const int blk = g * 64 + lane;
@@ -769,30 +784,34 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
             const float4 bb = tbox[blk];      // x min, x max, y min, y max
             on = !(bb.x - qbox[1] >= a.area || qbox[0] - bb.y >= a.area || bb.z - qbox[3] >= a.area || qbox[2] - bb.w >= a.area);
         }
-        live[g] = __ballot(on);
+        const unsigned long long mask = __ballot(on);
+        const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        if (on) s_list[wave][n_live + before] = (unsigned short)blk;
+        n_live += __builtin_popcountll(mask);
     }
-    // the next block of the list (-1: none); the masks are the same in every lane
-    auto next_block = [&]() {
-#pragma unroll
-        for (int g = 0; g < kWmGroups; g++) {
-            if (live[g] != 0ull) {
-                const int j = __builtin_ctzll(live[g]);
-                live[g] &= live[g] - 1ull;
-                return g * 64 + j;
-            }
-        }
-        return -1;
-    };
+#ifdef SA_WM_COUNT
+    if (lane == 0) {
+        atomicAdd(&g_wm_count[0], 1ull);
+        atomicAdd(&g_wm_count[1], (unsigned long long)n_live);
+        atomicAdd(&g_wm_count[2], (unsigned long long)((nblocks - split + a.splits - 1) / a.splits));
+        atomicMax(&g_wm_count[3], (unsigned long long)n_live);
+    }
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // entry i of the list (-1 past its end), the same in every lane
+    auto block_at = [&](int i) { return i < n_live ? __builtin_amdgcn_readfirstlane((int)s_list[wave][i]) : -1; };
 
     struct Fetched { uint4 rows; unsigned pos, word; };
-    // lane (r, h): dwords 4 h .. 4 h + 3 of the block's row r, its x (h = 0) or y, its index word; rows past the end of
-    // the set repeat the last one and are marked as failed below
-    auto fetch = [&](int blk, Fetched& f) {
+    // lane (r, h), in two steps: the x (h = 0) or y of the block's row r and its index word, then dwords 4 h .. 4 h + 3
+    // of the row that the word names; rows past the end of the set repeat the last one and are marked as failed below
+    auto fetch_meta = [&](int blk, Fetched& f) {
         const unsigned t = min((unsigned)(blk * kMmSub + r), (unsigned)(nt - 1));
-        f.rows = td[2 * t + h];
         f.pos = txy[2 * t + h];
         f.word = tidx[t];
     };
+    auto fetch_rows = [&](Fetched& f) { f.rows = td[2 * (f.word & (unsigned)(kWmMaxTrain - 1)) + h]; };
     // into LDS slice p: expanded rows as [step][half][row] of 16 bytes (dword d belongs to step d / 2, half d % 2),
     // positions, accumulator operands 2^15 + 32 * 256 + index / 256 (exact in a float); returns the mask of rows
     // above max_level
@@ -820,15 +839,23 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
         return ((u & ~0x1fffu) << 7) + (u & 0x1fffu);
     };
 
-    Fetched f;
-    int blk = next_block();
-    if (blk >= 0) fetch(blk, f);
+    // two blocks ahead: the index words of the block after the next are on their way while the next one's rows are
+    Fetched f, fn;
+    f.rows = make_uint4(0u, 0u, 0u, 0u);
+    int at = 2;
+    int blk = block_at(0), blk_n = block_at(1);
+    if (blk >= 0) fetch_meta(blk, f);
+    if (blk_n >= 0) fetch_meta(blk_n, fn);
+    if (blk >= 0) fetch_rows(f);
     int p = 0;
     while (blk >= 0) {
         const unsigned high = stage(p, f);
         const int rows_left = nt - blk * kMmSub;
-        blk = next_block();
-        if (blk >= 0) fetch(blk, f);       // in flight while this block is worked on
+        blk = blk_n;
+        f.pos = fn.pos; f.word = fn.word;
+        blk_n = block_at(at++);
+        if (blk_n >= 0) fetch_meta(blk_n, fn);
+        if (blk >= 0) fetch_rows(f);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

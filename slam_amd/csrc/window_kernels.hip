@@ -48,27 +48,82 @@ __device__ __forceinline__ float wave_max(float v) {
 // close together, not a global order, and chunks sort in parallel.
 constexpr int kChunkRows = 4096;
 constexpr int kRowsPerThread = kChunkRows / kSortBlock;
+// Row k of thread `tid` inside its chunk: neighbouring lanes take neighbouring rows.  (They usually lie in the same
+// grid cell -- an extractor leaves its rows ordered by position -- and their additions to the cell's counter are
+// served one after the other, 2.5 us of the kernel's 12 for 64 frames of 2000 rows; dealing the rows to lanes far
+// apart removes that and costs 4 us in the loads, which then touch 64 cache lines per instruction.)
+__device__ __forceinline__ int local_row(int k, int tid) { return k * kSortBlock + tid; }
 
 __global__ __launch_bounds__(kSortBlock) void spatial_sort_kernel(SpatialSortArgs a) {
     __shared__ int s_cell[kMaxCells];      // counts, then write cursors
     __shared__ float s_red[4][16];
     __shared__ int s_scan[16];
+    __shared__ float2 s_sxy[kChunkRows];   // positions and index words in their new order: written out row after row, and for the boxes
+    __shared__ unsigned s_sidx[kChunkRows];
     const int prob = blockIdx.y;
     const int set = (int)blockIdx.x >= a.qchunks ? 1 : 0;
     const int chunk = set == 0 ? blockIdx.x : blockIdx.x - a.qchunks;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     if (set == 0 && prob >= a.batch_q) return;
-    int n1 = a.n1, n2 = a.n2;
-    if (set == 0 && a.d_n1) n1 = min(n1, a.d_n1[prob]);
-    if (set == 1 && a.d_n2) n2 = min(n2, a.d_n2[prob]);
-    const int n = set == 0 ? (a.ids ? a.n_ids : n1) : n2;
+    // Everything a thread needs of its rows -- position, octave, descriptor -- is requested at once, by the host's
+    // bound on the set (rows past the bound repeat the last one below it); the set's true count, in device memory,
+    // is looked at after the requests are out, so that the kernel waits for memory once and not three times.
+    const int nb = set == 0 ? (a.ids ? a.n_ids : a.n1) : a.n2;
     const int c0 = chunk * kChunkRows;
-    if (c0 >= n) return;
-    const int cn = min(kChunkRows, n - c0);   // rows of this chunk
+    if (c0 >= nb) return;
+    const int32_t* const d_n = set == 0 ? a.d_n1 : a.d_n2;
     const size_t base = (size_t)prob * (set == 0 ? a.cap1 : a.cap2);  // first row of the problem's set
     const uint8_t* desc = set == 0 ? a.qdesc : a.tdesc;
     const slam_amd_keypoint* kp = set == 0 ? a.qkp : a.tkp;
+    const bool gather = set == 0 && a.ids;
+    const bool own_xy = set == 0 && a.q_xy;
+
+    float2 p[kRowsPerThread];
+    // (the descriptors as two vectors of 16 dwords, four per row: an array of uint4 ends up in scratch memory here)
+    typedef unsigned u16v __attribute__((ext_vector_type(16)));
+    static_assert(kRowsPerThread == 4, "four rows per thread");
+    u16v d0 = 0u, d1 = 0u;
+    int oct[kRowsPerThread];
+    // (one loop per kind of load, the conditions outside: inside one loop the compiler waits for every row's loads
+    // before it asks for the next row's)
+    int src[kRowsPerThread];
+    size_t row[kRowsPerThread];
+#pragma unroll
+    for (int k = 0; k < kRowsPerThread; k++) src[k] = min(c0 + local_row(k, tid), nb - 1);
+    if (own_xy) {
+#pragma unroll
+        for (int k = 0; k < kRowsPerThread; k++) p[k] = reinterpret_cast<const float2*>(a.q_xy)[base + src[k]];
+    }
+    if (gather) {
+#pragma unroll
+        for (int k = 0; k < kRowsPerThread; k++) src[k] = a.ids[src[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < kRowsPerThread; k++) row[k] = base + (size_t)src[k];
+    if (a.copy_desc) {
+#pragma unroll
+      for (int k = 0; k < kRowsPerThread; k++) {
+        const uint4* d = reinterpret_cast<const uint4*>(desc + row[k] * 32);
+        const uint4 lo = d[0], hi = d[1];
+        d0[4 * k] = lo.x; d0[4 * k + 1] = lo.y; d0[4 * k + 2] = lo.z; d0[4 * k + 3] = lo.w;
+        d1[4 * k] = hi.x; d1[4 * k + 1] = hi.y; d1[4 * k + 2] = hi.z; d1[4 * k + 3] = hi.w;
+      }
+    }
+    if (!own_xy) {
+#pragma unroll
+        for (int k = 0; k < kRowsPerThread; k++) p[k] = make_float2(kp[row[k]].x, kp[row[k]].y);
+    }
+#pragma unroll
+    for (int k = 0; k < kRowsPerThread; k++) oct[k] = 0;
+    if (a.max_level != -1) {
+#pragma unroll
+        for (int k = 0; k < kRowsPerThread; k++) oct[k] = kp[row[k]].octave;
+    }
+    int n = nb;
+    if (d_n) n = set == 0 && a.ids ? nb : min(nb, d_n[prob]);      // (with ids, the count of set 1 does not bound the queries)
+    if (c0 >= n) return;
+    const int cn = min(kChunkRows, n - c0);   // rows of this chunk
     const int scap = a.scap[set];
     uint4* sdesc = a.sdesc[set] + ((size_t)prob * scap + c0) * 2;
     float2* sxy = a.sxy[set] + (size_t)prob * scap + c0;
@@ -76,29 +131,22 @@ __global__ __launch_bounds__(kSortBlock) void spatial_sort_kernel(SpatialSortArg
     const int box_rows = a.box_rows;      // 64 or 32
     float4* box = a.tile_box[set] + (size_t)prob * (scap / box_rows) + c0 / box_rows;
 
-    // this thread's rows: position, source row and index word stay in registers
-    float2 p[kRowsPerThread];
-    size_t row[kRowsPerThread];
     unsigned idx[kRowsPerThread];
     float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
 #pragma unroll
     for (int k = 0; k < kRowsPerThread; k++) {
-        const int li = k * kSortBlock + tid;
-        p[k] = make_float2(NAN, NAN);
-        row[k] = 0;
+        const int li = local_row(k, tid);
         idx[k] = 0;
         if (li < cn) {
-            const int i = c0 + li;
-            row[k] = base + (size_t)((set == 0 && a.ids) ? a.ids[i] : i);
-            if (set == 0 && a.q_xy) p[k] = make_float2(a.q_xy[2 * (base + i)], a.q_xy[2 * (base + i) + 1]);
-            else p[k] = make_float2(kp[row[k]].x, kp[row[k]].y);
-            idx[k] = (unsigned)i;
-            if (a.max_level != -1 && kp[row[k]].octave > a.max_level) idx[k] |= kHighFlag;
+            idx[k] = (unsigned)(c0 + li);
+            if (a.max_level != -1 && oct[k] > a.max_level) idx[k] |= kHighFlag;
             if (finite2(p[k].x, p[k].y)) {
                 const float cx = cell_coord(p[k].x), cy = cell_coord(p[k].y);
                 xmin = fminf(xmin, cx); xmax = fmaxf(xmax, cx);
                 ymin = fminf(ymin, cy); ymax = fmaxf(ymax, cy);
             }
+        } else {
+            p[k] = make_float2(NAN, NAN);
         }
     }
     xmin = wave_min(xmin); xmax = wave_max(xmax); ymin = wave_min(ymin); ymax = wave_max(ymax);
@@ -119,17 +167,18 @@ __global__ __launch_bounds__(kSortBlock) void spatial_sort_kernel(SpatialSortArg
     // Any mapping position -> cell gives a correct result; this one keeps neighbours
     // together: cells in rows, every other row of cells walked right to left so that
     // consecutive cells always touch.
-    int cell[kRowsPerThread];
+    int cell[kRowsPerThread], rank[kRowsPerThread] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < kRowsPerThread; k++) {
         cell[k] = 0;
-        if (k * kSortBlock + tid < cn && finite2(p[k].x, p[k].y)) {
+        if (local_row(k, tid) < cn && finite2(p[k].x, p[k].y)) {
             int cx = (int)fminf(fmaxf((cell_coord(p[k].x) - xmin) * icw, 0.f), (float)(ncx - 1));
             const int cy = (int)fminf(fmaxf((cell_coord(p[k].y) - ymin) * ich, 0.f), (float)(ncy - 1));
             if (cy & 1) cx = ncx - 1 - cx;
             cell[k] = cy * ncx + cx;
         }
-        if (k * kSortBlock + tid < cn) atomicAdd(&s_cell[cell[k]], 1);
+        // the row's rank among the rows of its cell (whichever order the additions land in)
+        if (local_row(k, tid) < cn) rank[k] = atomicAdd(&s_cell[cell[k]], 1);
     }
     __syncthreads();
     // exclusive scan of the cell counts: four consecutive cells per thread
@@ -154,24 +203,25 @@ __global__ __launch_bounds__(kSortBlock) void spatial_sort_kernel(SpatialSortArg
     // scatter; the order inside a cell is arbitrary, which does not change any result
 #pragma unroll
     for (int k = 0; k < kRowsPerThread; k++) {
-        if (k * kSortBlock + tid >= cn) continue;
-        const int pos = atomicAdd(&s_cell[cell[k]], 1);
-        const uint4* d = reinterpret_cast<const uint4*>(desc + row[k] * 32);
-        sdesc[2 * pos] = d[0];
-        sdesc[2 * pos + 1] = d[1];
-        sxy[pos] = p[k];
-        sidx[pos] = idx[k];
+        if (local_row(k, tid) >= cn) continue;
+        const int pos = s_cell[cell[k]] + rank[k];
+        if (a.copy_desc) {
+            sdesc[2 * pos] = make_uint4(d0[4 * k], d0[4 * k + 1], d0[4 * k + 2], d0[4 * k + 3]);
+            sdesc[2 * pos + 1] = make_uint4(d1[4 * k], d1[4 * k + 1], d1[4 * k + 2], d1[4 * k + 3]);
+        }
+        s_sxy[pos] = p[k];
+        s_sidx[pos] = idx[k];
     }
-    if (set == 0) return;  // query waves compute their own box
-    __threadfence_block();
     __syncthreads();
+    for (int i = tid; i < cn; i += kSortBlock) { sxy[i] = s_sxy[i]; sidx[i] = s_sidx[i]; }
+    if (set == 0) return;  // query waves compute their own box
 
     const int ntiles = (cn + 63) / 64;
     for (int t = wave; t < ntiles; t += kSortBlock / 64) {
         const int i = t * 64 + lane;
         float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
         if (i < cn) {
-            const float2 q = sxy[i];
+            const float2 q = s_sxy[i];
             if (finite2(q.x, q.y)) { bx0 = bx1 = q.x; by0 = by1 = q.y; }
         }
         for (int o = box_rows >> 1; o > 0; o >>= 1) {
