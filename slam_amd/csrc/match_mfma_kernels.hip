@@ -668,11 +668,27 @@ extern "C" int slam_amd_debug_mm_stamps(unsigned long long* out, int n_waves) {
 // [2^15, 2^16) has left), so the bit patterns order like (distance, original index) across all blocks and the
 // running minimum is a plain unsigned minimum.  Train sets of up to 2^13 rows.
 // =============================================================================
-constexpr int kWmWaves = 4;
+#ifndef SA_WM_WAVES
+#define SA_WM_WAVES 4
+#endif
+#ifndef SA_WM_NB
+#define SA_WM_NB 1
+#endif
+constexpr int kWmWaves = SA_WM_WAVES;         // waves per workgroup (they share nothing)
+constexpr int kWmNB = SA_WM_NB;               // query blocks of 32 per wave
+constexpr int kWmQueries = 32 * kWmNB;        // queries per wave
 constexpr int kWmIdxBits = 13;
 constexpr int kWmMaxTrain = 1 << kWmIdxBits;
-constexpr int kWmGroups = kWmMaxTrain / kMmSub / 64;      // 64-bit masks of live blocks per wave
+constexpr int kWmGroups = kWmMaxTrain / kMmSub / 64;      // groups of 64 train blocks (one box test per lane)
 
+#ifdef SA_WM_STAMPS
+// Diagnostic build only, per wave: shader clock at the start, at the first block and at the end, blocks worked on,
+// cycles spent waiting for the fetches at the top of the block loop, hardware id.
+__device__ unsigned long long g_wm_stamps[8192][6];
+extern "C" int slam_amd_debug_wm_stamps(unsigned long long* out, int n_waves) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wm_stamps), (size_t)n_waves * 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef SA_WM_COUNT
 // Diagnostic build only: waves that ran, train blocks they worked on, train blocks they could have, the longest list.
 __device__ unsigned long long g_wm_count[4];
@@ -683,18 +699,42 @@ extern "C" int slam_amd_debug_wm_count(unsigned long long* out, int reset) {
 }
 #endif
 
+// Minimum / maximum over the 32 lanes of a lane half, left in every lane of the wave (both halves hold the same
+// values here): four steps inside the rows of 16 lanes on the data-parallel path (lane ^ 1, lane ^ 2, mirrored
+// halves of 8, mirrored rows), then the two rows of a half through scalar registers.
+template <bool MAX>
+__device__ __forceinline__ float half_reduce(float v) {
+    auto step = [&](float o) { v = MAX ? fmaxf(v, o) : fminf(v, o); };
+    auto dpp = [&](auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    step(dpp(std::integral_constant<int, 0xB1>()));      // quad_perm [1, 0, 3, 2]
+    step(dpp(std::integral_constant<int, 0x4E>()));      // quad_perm [2, 3, 0, 1]
+    step(dpp(std::integral_constant<int, 0x141>()));     // row_half_mirror
+    step(dpp(std::integral_constant<int, 0x140>()));     // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    return MAX ? fmaxf(r0, r1) : fminf(r0, r1);
+}
+
 template <bool LEVEL, bool SECOND>
-__global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(WindowMatchArgs a) {
+__global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(WindowMatchArgs a) {
     __shared__ uint4 s_rows[kWmWaves][2][kMmSubU4];                       // a block's expanded rows, two deep per wave
     __shared__ __align__(16) float s_pos[kWmWaves][2][3][kMmSub];         // its rows' x, y and accumulator operand
     __shared__ unsigned short s_list[kWmWaves][kWmMaxTrain / kMmSub];     // the train blocks a wave works on
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    // problem fastest, then the split of the train blocks, then the group of four query tiles
-    const int prob = blockIdx.x % a.batch;
-    const int rest = blockIdx.x / a.batch;
-    const int split = rest % a.splits;
-    const int qtile = (rest / a.splits) * kWmWaves + wave;
+#ifdef SA_WM_STAMPS
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
+    unsigned long long stamp_wait = 0;
+#endif
+    // waves in the order (query tile, problem, split of the train blocks), the split fastest: the waves of a workgroup
+    // share their queries when there are splits, and finish together
+    const long long wid = (long long)blockIdx.x * kWmWaves + wave;
+    const int split = (int)(wid % a.splits);
+    const long long rest = wid / a.splits;
+    const int prob = (int)(rest % a.batch);
+    const int qtile = (int)(rest / a.batch);
 
     // the query side: the problem's own rows of set 0, or, in a chained batch, the frame before (set 0 holds the one
     // before the batch)
@@ -704,11 +744,8 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
         if (prob == 0) { qcount = a.d_n1; }
         else { qset = 1; qprob = prob - 1; nqb = a.n2; qcount = a.d_n2 ? a.d_n2 + (prob - 1) : nullptr; }
     }
-    int n1 = nqb, nt = a.n2;
-    if (qcount) n1 = min(n1, *qcount);
-    if (a.d_n2) nt = min(nt, a.d_n2[prob]);
-    const int nq = a.has_ids ? a.n_ids : n1;
-    if (qtile * 64 >= nq || nt <= 0) return;      // (no workgroup barrier below: the waves are on their own)
+    const int nq_bound = a.has_ids ? a.n_ids : nqb;
+    if (qtile * kWmQueries >= nq_bound || a.n2 <= 0) return;      // (no workgroup barrier below: the waves are on their own)
 
     // the descriptors stay where the caller holds them and are fetched through the index words
     const uint4* const qd = reinterpret_cast<const uint4*>(qset == 0 ? a.qdesc : a.tdesc) +
@@ -720,70 +757,76 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
     const uint32_t* const tidx = a.sidx[1] + (size_t)prob * a.scap[1];
     const float4* const tbox = a.tile_box + (size_t)prob * (a.scap[1] / kMmSub);
 
-    // ---- this wave's queries: both lane halves hold the same 32 per block, half h the dwords 2s + h of product s ----
-    v4i bq[kMmNB][kMmSteps];
-    int pq[kMmNB];
-    float qx[kMmNB], qy[kMmNB];
-    unsigned qword[kMmNB];
-    bool qvalid[kMmNB], qhigh[kMmNB];
+    // ---- first round of loads, all by the host's bounds (the counts in device memory are among them): the queries'
+    //      index words and positions, the boxes of the train blocks.  What lies between a count and its bound has
+    //      never been written: an index word from there is brought into range before it is used as an index ----
+    unsigned qword[kWmNB];
+    float2 qpos[kWmNB];
+#pragma unroll
+    for (int b = 0; b < kWmNB; b++) {
+        const int qc = min(qtile * kWmQueries + b * 32 + r, nq_bound - 1);
+        qword[b] = qidx[qc];
+        qpos[b] = qxy[qc];
+    }
+    // (lane l of group g looks at the block (64 g + l) * splits + split: this split's blocks only)
+    const int nblocks_bound = (a.n2 + kMmSub - 1) / kMmSub;
+    float4 bb[kWmGroups];
+#pragma unroll
+    for (int g = 0; g < kWmGroups; g++)
+        if (g * 64 * a.splits < nblocks_bound)
+            bb[g] = tbox[min((g * 64 + lane) * a.splits + split, nblocks_bound - 1)];      // x min, x max, y min, y max
+    int n1 = nqb, nt = a.n2;
+    if (qcount) n1 = min(n1, *qcount);
+    if (a.d_n2) nt = min(nt, a.d_n2[prob]);
+    const int nq = a.has_ids ? a.n_ids : n1;
+
+    // ---- second round: the queries' descriptors.  Both lane halves hold the same 32 queries per block, half h 16
+    //      bytes of the row (dwords 4 h .. 4 h + 3) ----
+    uint4 own[kWmNB];
+#pragma unroll
+    for (int b = 0; b < kWmNB; b++) {
+        int qsrc = (int)min(qword[b] & 0x7fffffffu, (unsigned)(nq_bound - 1));
+        if (a.ids) qsrc = a.ids[qsrc];
+        own[b] = qd[2 * qsrc + h];
+    }
+    if (qtile * kWmQueries >= nq || nt <= 0) return;
+
+    // ---- the train blocks this wave has to look at, while the descriptors are on their way: lane l tests block
+    //      64 g + l.  fl(a - b) is monotone in a and in b, so when the nearest edges of the two boxes are a window
+    //      apart, every pair of their points is ----
+    float qx[kWmNB], qy[kWmNB];
+    bool qvalid[kWmNB], qhigh[kWmNB];
     bool any_qhigh = false;
     const float inf = __uint_as_float(0x7f800000u);
     float qbox[4] = {inf, -inf, inf, -inf};      // x min, x max, y min, y max of the queries with finite positions
 #pragma unroll
-    for (int b = 0; b < kMmNB; b++) {
-        const int qi = qtile * 64 + b * 32 + r;
-        qvalid[b] = qi < nq;
-        const int qc = min(qi, nq - 1);
-        qword[b] = qidx[qc];
-        const float2 p = qxy[qc];
-        int qsrc = (int)(qword[b] & 0x7fffffffu);
-        if (a.ids) qsrc = a.ids[qsrc];
-        const uint4 own = qd[2 * qsrc + h];
-        // 16 bytes of the row per lane half (dwords 4 h .. 4 h + 3); product s takes dword 2 s + h, so either half
-        // hands two of its dwords to the other
-        const unsigned give0 = h ? own.x : own.y, give1 = h ? own.z : own.w;
-        const unsigned take0 = (unsigned)__shfl_xor((int)give0, 32, 64), take1 = (unsigned)__shfl_xor((int)give1, 32, 64);
-        const unsigned qw[kMmSteps] = {h ? take0 : own.x, h ? take1 : own.z, h ? own.y : take0, h ? own.w : take1};
-        int pc = 0;
-#pragma unroll
-        for (int s = 0; s < kMmSteps; s++) {
-            pc += __builtin_popcount(qw[s]);
-            bq[b][s] = expand_query(qw[s]);
-        }
-        pq[b] = pc + __shfl_xor(pc, 32, 64);
+    for (int b = 0; b < kWmNB; b++) {
+        qvalid[b] = qtile * kWmQueries + b * 32 + r < nq;
         qhigh[b] = LEVEL && qvalid[b] && (qword[b] >> 31) != 0u;
         qword[b] &= 0x7fffffffu;
         any_qhigh = any_qhigh || (LEVEL && __ballot(qhigh[b]) != 0ull);
+        const float2 p = qpos[b];
         qx[b] = p.x; qy[b] = p.y;
-        const bool odd = (__float_as_uint(p.x) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(p.y) & 0x7f800000u) == 0x7f800000u;
-        if (odd) {
-            // a position that is NaN or infinite fails the window with every train row: -infinity here, +infinity on the
-            // train side, so that no difference is ever a NaN (the window test takes a maximum, which would drop one)
-            if ((__float_as_uint(p.x) & 0x7f800000u) == 0x7f800000u) qx[b] = -inf;
-            if ((__float_as_uint(p.y) & 0x7f800000u) == 0x7f800000u) qy[b] = -inf;
-        } else if (qvalid[b]) {
+        const bool oddx = (__float_as_uint(p.x) & 0x7f800000u) == 0x7f800000u, oddy = (__float_as_uint(p.y) & 0x7f800000u) == 0x7f800000u;
+        // a position that is NaN or infinite fails the window with every train row: -infinity here, +infinity on the
+        // train side, so that no difference is ever a NaN (the window test takes a maximum, which would drop one)
+        if (oddx) qx[b] = -inf;
+        if (oddy) qy[b] = -inf;
+        if (!oddx && !oddy && qvalid[b]) {
             qbox[0] = fminf(qbox[0], p.x); qbox[1] = fmaxf(qbox[1], p.x);
             qbox[2] = fminf(qbox[2], p.y); qbox[3] = fmaxf(qbox[3], p.y);
         }
     }
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-        qbox[0] = fminf(qbox[0], __shfl_xor(qbox[0], d, 64)); qbox[1] = fmaxf(qbox[1], __shfl_xor(qbox[1], d, 64));
-        qbox[2] = fminf(qbox[2], __shfl_xor(qbox[2], d, 64)); qbox[3] = fmaxf(qbox[3], __shfl_xor(qbox[3], d, 64));
-    }
-
-    // ---- the train blocks this wave has to look at: lane l tests block 64 g + l.  fl(a - b) is monotone in a and in
-    //      b, so when the nearest edges of the two boxes are a window apart, every pair of their points is ----
+    qbox[0] = half_reduce<false>(qbox[0]); qbox[1] = half_reduce<true>(qbox[1]);
+    qbox[2] = half_reduce<false>(qbox[2]); qbox[3] = half_reduce<true>(qbox[3]);
     const int nblocks = (nt + kMmSub - 1) / kMmSub;
     int n_live = 0;      // the list goes through LDS: walking bit masks costs more instructions than the list has entries
 #pragma unroll
     for (int g = 0; g < kWmGroups; g++) {
-        const int blk = g * 64 + lane;
-        bool on = blk < nblocks && (blk % a.splits) == split;
-        if (on) {
-            const float4 bb = tbox[blk];      // x min, x max, y min, y max
-            on = !(bb.x - qbox[1] >= a.area || qbox[0] - bb.y >= a.area || bb.z - qbox[3] >= a.area || qbox[2] - bb.w >= a.area);
-        }
+        if (g * 64 * a.splits >= nblocks_bound) continue;
+        const int blk = (g * 64 + lane) * a.splits + split;
+        const bool on = blk < nblocks &&
+                        !(bb[g].x - qbox[1] >= a.area || qbox[0] - bb[g].y >= a.area || bb[g].z - qbox[3] >= a.area || qbox[2] - bb[g].w >= a.area);
         const unsigned long long mask = __ballot(on);
         const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         if (on) s_list[wave][n_live + before] = (unsigned short)blk;
@@ -805,23 +848,50 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
 
     struct Fetched { uint4 rows; unsigned pos, word; };
     // lane (r, h), in two steps: the x (h = 0) or y of the block's row r and its index word, then dwords 4 h .. 4 h + 3
-    // of the row that the word names; rows past the end of the set repeat the last one and are marked as failed below
+    // of the row that the word names.  Rows past the end of the set repeat the last one; their position becomes
+    // +infinity, which fails the window with every query
     auto fetch_meta = [&](int blk, Fetched& f) {
         const unsigned t = min((unsigned)(blk * kMmSub + r), (unsigned)(nt - 1));
         f.pos = txy[2 * t + h];
         f.word = tidx[t];
     };
     auto fetch_rows = [&](Fetched& f) { f.rows = td[2 * (f.word & (unsigned)(kWmMaxTrain - 1)) + h]; };
+    // two blocks ahead: the index words of the block after the next are on their way while the next one's rows are
+    Fetched f, fn;
+    f.rows = make_uint4(0u, 0u, 0u, 0u);
+    int at = 2;
+    int blk = block_at(0), blk_n = block_at(1);
+    if (blk >= 0) fetch_meta(blk, f);
+    if (blk_n >= 0) fetch_meta(blk_n, fn);
+
+    // ---- the queries, expanded once: product s takes dword 2 s + h, so either half hands two of its dwords to the other ----
+    v4i bq[kWmNB][kMmSteps];
+    int pq[kWmNB];
+#pragma unroll
+    for (int b = 0; b < kWmNB; b++) {
+        const unsigned give0 = h ? own[b].x : own[b].y, give1 = h ? own[b].z : own[b].w;
+        const unsigned take0 = (unsigned)__shfl_xor((int)give0, 32, 64), take1 = (unsigned)__shfl_xor((int)give1, 32, 64);
+        const unsigned qw[kMmSteps] = {h ? take0 : own[b].x, h ? take1 : own[b].z, h ? own[b].y : take0, h ? own[b].w : take1};
+        int pc = 0;
+#pragma unroll
+        for (int s = 0; s < kMmSteps; s++) {
+            pc += __builtin_popcount(qw[s]);
+            bq[b][s] = expand_query(qw[s]);
+        }
+        pq[b] = pc + __shfl_xor(pc, 32, 64);
+    }
+    if (blk >= 0) fetch_rows(f);
+
     // into LDS slice p: expanded rows as [step][half][row] of 16 bytes (dword d belongs to step d / 2, half d % 2),
     // positions, accumulator operands 2^15 + 32 * 256 + index / 256 (exact in a float); returns the mask of rows
     // above max_level
-    auto stage = [&](int p, const Fetched& f) {
+    auto stage = [&](int p, const Fetched& f, int rows_left) {
         uint4* const dst = s_rows[wave][p];
         dst[(4 * h) * 32 + r] = expand_train(f.rows.x);
         dst[(4 * h + 1) * 32 + r] = expand_train(f.rows.y);
         dst[(4 * h + 2) * 32 + r] = expand_train(f.rows.z);
         dst[(4 * h + 3) * 32 + r] = expand_train(f.rows.w);
-        const bool odd = (f.pos & 0x7f800000u) == 0x7f800000u;
+        const bool odd = (f.pos & 0x7f800000u) == 0x7f800000u || r >= rows_left;
         s_pos[wave][p][h][r] = __uint_as_float(odd ? 0x7f800000u : f.pos);
         if (h == 0) s_pos[wave][p][2][r] = (float)kMmBias + (float)(f.word & (unsigned)(kWmMaxTrain - 1)) * (1.f / 256.f);
         return LEVEL ? (unsigned)__ballot((f.word >> 31) != 0u) : 0u;
@@ -830,27 +900,25 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
     int scale_a = kMmScaleOne, scale_b = kMmScale64;
     asm volatile("" : "+v"(scale_a), "+v"(scale_b));
     const int area_bits_m1 = (int)__float_as_uint(a.area) - 1;
-    unsigned best[kMmNB], second[kMmNB];
+    unsigned best[kWmNB], second[kWmNB];
 #pragma unroll
-    for (int b = 0; b < kMmNB; b++) best[b] = second[b] = kMmNoMatch;
+    for (int b = 0; b < kWmNB; b++) best[b] = second[b] = kMmNoMatch;
     // pattern -> key Hb << 20 | original index (a pattern with the failure mark: Hb = 1023)
     auto bits_key = [](unsigned bits) {
         const unsigned u = min(bits - kMmBinade, 0x7fffffu);
         return ((u & ~0x1fffu) << 7) + (u & 0x1fffu);
     };
 
-    // two blocks ahead: the index words of the block after the next are on their way while the next one's rows are
-    Fetched f, fn;
-    f.rows = make_uint4(0u, 0u, 0u, 0u);
-    int at = 2;
-    int blk = block_at(0), blk_n = block_at(1);
-    if (blk >= 0) fetch_meta(blk, f);
-    if (blk_n >= 0) fetch_meta(blk_n, fn);
-    if (blk >= 0) fetch_rows(f);
     int p = 0;
+#ifdef SA_WM_STAMPS
+    const unsigned long long stamp1 = __builtin_amdgcn_s_memtime();
+#endif
     while (blk >= 0) {
-        const unsigned high = stage(p, f);
-        const int rows_left = nt - blk * kMmSub;
+#ifdef SA_WM_STAMPS
+        { const unsigned long long ta = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          stamp_wait += __builtin_amdgcn_s_memtime() - ta; }
+#endif
+        const unsigned high = stage(p, f, nt - blk * kMmSub);
         blk = blk_n;
         f.pos = fn.pos; f.word = fn.word;
         blk_n = block_at(at++);
@@ -860,7 +928,7 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        v16f acc[kMmNB];
+        v16f acc[kWmNB];
         {
             v16f cin;
 #pragma unroll
@@ -872,23 +940,22 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
             for (int s = 0; s < kMmSteps; s++) {
                 const v4i af = *reinterpret_cast<const v4i*>(&s_rows[wave][p][s * 64 + h * 32 + r]);
 #pragma unroll
-                for (int b = 0; b < kMmNB; b++) acc[b] = product(af, bq[b][s], s == 0 ? cin : acc[b], scale_a, scale_b);
+                for (int b = 0; b < kWmNB; b++) acc[b] = product(af, bq[b][s], s == 0 ? cin : acc[b], scale_a, scale_b);
             }
         }
         // ---- gates, as in match_mfma_kernel: the sign of (bits(area) - 1) - bits(max(|dx|, |dy|)) is "not inside
-        //      the window"; bit `row` of the block's mask of high rows for queries that are high themselves; rows past
-        //      the end of the set ----
+        //      the window"; bit `row` of the block's mask of high rows for queries that are high themselves ----
         auto gates = [&](auto level_on) {
             constexpr bool kLevelOn = LEVEL && decltype(level_on)::value;
-            unsigned mine[kMmNB];
+            unsigned mine[kWmNB];
 #pragma unroll
-            for (int b = 0; b < kMmNB; b++) mine[b] = (kLevelOn && qhigh[b]) ? high >> (4 * h) : 0u;
+            for (int b = 0; b < kWmNB; b++) mine[b] = (kLevelOn && qhigh[b]) ? high >> (4 * h) : 0u;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const v4f x4 = *reinterpret_cast<const v4f*>(&s_pos[wave][p][0][8 * j + 4 * h]);
                 const v4f y4 = *reinterpret_cast<const v4f*>(&s_pos[wave][p][1][8 * j + 4 * h]);
 #pragma unroll
-                for (int b = 0; b < kMmNB; b++)
+                for (int b = 0; b < kWmNB; b++)
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
                         const int i = 4 * j + c;
@@ -902,16 +969,9 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
         };
         if (LEVEL && high != 0u && any_qhigh) gates(std::true_type());
         else gates(std::false_type());
-        if (rows_left < kMmSub) {
-#pragma unroll
-            for (int b = 0; b < kMmNB; b++)
-#pragma unroll
-                for (int i = 0; i < 16; i++)
-                    if (acc_row(i, h) >= rows_left) acc_fail(acc[b], i);
-        }
         // ---- the block's minimum (two smallest with SECOND) into the running one ----
 #pragma unroll
-        for (int b = 0; b < kMmNB; b++) {
+        for (int b = 0; b < kWmNB; b++) {
             if (!SECOND) {
                 unsigned m = best[b];
 #pragma unroll
@@ -933,9 +993,16 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
         }
         p ^= 1;
     }
+#ifdef SA_WM_STAMPS
+    if (lane == 0) {
+        unsigned long long* o = g_wm_stamps[wid & 8191];
+        o[0] = stamp0; o[1] = stamp1; o[2] = __builtin_amdgcn_s_memtime(); o[3] = (unsigned long long)n_live; o[4] = stamp_wait;
+        o[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    }
+#endif
 
 #pragma unroll
-    for (int b = 0; b < kMmNB; b++) {
+    for (int b = 0; b < kWmNB; b++) {
         const unsigned mine = SECOND ? best[b] : bits_key(best[b]);
         const unsigned ob = (unsigned)__shfl_xor((int)mine, 32, 64);
         const unsigned m = min(mine, ob);
@@ -959,19 +1026,23 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void match_window_mfma_kernel(Win
 
 int window_mfma_max_train() { return kWmMaxTrain; }
 
-// Waves of 64 queries are the unit of work; the train blocks are dealt round-robin to `splits` waves per query tile
-// only when the query tiles alone leave SIMDs without a second wave (a split expands its queries again).
+// A wave and its queries are the unit of work; the train blocks are dealt round-robin to `splits` waves per query
+// tile only when the query tiles alone leave the SIMDs short of waves (a split expands its queries again).
 int window_mfma_splits(int batch, int nq_bound, int nt_bound, int n_cu) {
-    const long long qwaves = (long long)div_up(nq_bound, 64) * batch;
+    const long long qwaves = (long long)div_up(nq_bound, kWmQueries) * batch;
     if (qwaves <= 0) return 1;
-    const long long want = div_up(n_cu * 8, (int)std::min<long long>(qwaves, 1 << 30));
+    long long want = div_up(n_cu * 16, (int)std::min<long long>(qwaves, 1 << 30));
+#ifdef SA_WM_SPLITS
+    want = SA_WM_SPLITS;      // timing experiments
+#endif
     return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(want, kMaxSecondSplits), div_up(nt_bound, 4 * kMmSub)));
 }
 
 int launch_match_window_mfma(const WindowMatchArgs& a, int batch, int nq_bound, hipStream_t st) {
     if (a.n2 > kWmMaxTrain || !(a.area > 0.f) || a.splits < 1)
         SA_FAIL(SLAM_AMD_ERR_ARG, "match: the reordered matrix-core kernel takes a window and at most 8192 train rows");
-    const long long blocks = (long long)div_up(div_up(nq_bound, 64), kWmWaves) * a.splits * batch;
+    const long long waves = (long long)div_up(nq_bound, kWmQueries) * a.splits * batch;
+    const long long blocks = (waves + kWmWaves - 1) / kWmWaves;
     if (blocks <= 0) return SLAM_AMD_OK;
     if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match: problem too large for one launch");
     const dim3 grid((unsigned)blocks), block(kWmWaves * 64);
