@@ -1194,6 +1194,39 @@ extern "C" int slam_amd_match_pairs_async(slam_amd_matcher* m,
     if (m->ratio > 0.f || m->histo_length > 0)
         SA_FAIL(SLAM_AMD_ERR_UNSUPPORTED, "match_pairs does not apply the ratio / rotation options; clear them first");
     SA_HIP(hipSetDevice(m->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // With the window gate on, the keyframes are first reordered by grid cell (index words and positions in the
+    // matcher's scratch) and every pair goes through the kernel that only looks at the train blocks near a wave's
+    // queries; same result.
+    if (m->sweep_kernel == 0 && m->window_mode != 1 && area > 0.f && area <= 3.0e38f && n_per <= window_mfma_max_train() && n_pairs > 0) {
+        const SortedLayout lay = sorted_layout(n_keyframes, 0, n_per);
+        int rc;
+        if ((rc = grow_scratch(m, m->sorted, lay.total, stream_capturing(st)))) return rc;
+        uint8_t* basep = m->sorted.as<uint8_t>();
+        SpatialSortArgs sa_;
+        memset(&sa_, 0, sizeof sa_);
+        sa_.tdesc = d_desc; sa_.tkp = d_kp; sa_.n2 = n_per; sa_.cap2 = n_per;
+        sa_.area = area; sa_.max_level = max_level;
+        sa_.scap[0] = lay.scap[0]; sa_.scap[1] = lay.scap[1];
+        sa_.box_rows = 32; sa_.copy_desc = 0;
+        WindowMatchArgs w;
+        memset(&w, 0, sizeof w);
+        for (int s = 0; s < 2; s++) {
+            sa_.sdesc[s] = reinterpret_cast<uint4*>(basep + lay.o_desc[s]);
+            sa_.sxy[s] = reinterpret_cast<float2*>(basep + lay.o_xy[s]);
+            sa_.sidx[s] = reinterpret_cast<uint32_t*>(basep + lay.o_idx[s]);
+            sa_.tile_box[s] = reinterpret_cast<float4*>(basep + lay.o_box[s]);
+            w.sdesc[s] = sa_.sdesc[s]; w.sxy[s] = sa_.sxy[s]; w.sidx[s] = sa_.sidx[s]; w.scap[s] = sa_.scap[s];
+        }
+        { ProfScope ps(kStageSpatialSort, st); if ((rc = launch_spatial_sort(sa_, n_keyframes, 0, n_per, st))) return rc; }
+        w.tile_box = sa_.tile_box[1];
+        w.n1 = n_per; w.n2 = n_per; w.cap1 = n_per; w.cap2 = n_per;
+        w.area = area; w.max_level = max_level; w.batch = n_pairs; w.splits = 1;
+        w.qdesc = d_desc; w.tdesc = d_desc;
+        w.pairs = d_pairs; w.pair_out = d_out; w.dmax = dmax_of(max_dist);
+        ProfScope ps(kStageMatchPairs, st);
+        return launch_match_window_mfma(w, n_pairs, n_per, st);
+    }
     MatchArgs a;
     memset(&a, 0, sizeof a);
     a.qdesc = d_desc; a.qkp = d_kp; a.tdesc = d_desc; a.tkp = d_kp;

@@ -186,6 +186,11 @@ struct WindowMatchArgs {
     const uint8_t* tdesc;
     const int32_t* ids;       // the caller's gather of set-1 rows, or null
     int cap2;                 // rows between consecutive problems in tdesc (cap1: in qdesc)
+    // pair mode (matrix-core kernel): problem p matches keyframe pairs[2p] (queries) against keyframe pairs[2p + 1],
+    // both in set 1 (n2 rows each, no counts); every query's result goes to pair_out, no splits
+    const int32_t* pairs;
+    uint32_t* pair_out;       // [n_pairs][n2]  distance << 16 | train index, or 0xffffffff
+    int dmax;
 };
 
 struct FinalizeArgs {

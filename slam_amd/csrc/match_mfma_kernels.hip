@@ -738,24 +738,27 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
 
     // the query side: the problem's own rows of set 0, or, in a chained batch, the frame before (set 0 holds the one
     // before the batch)
-    int qset = 0, qprob = prob, nqb = a.n1;
+    int qset = 0, qprob = prob, tprob = prob, nqb = a.n1;
     const int32_t* qcount = a.d_n1 ? a.d_n1 + prob : nullptr;
+    const int32_t* tcount = a.d_n2 ? a.d_n2 + prob : nullptr;
     if (a.chain) {
         if (prob == 0) { qcount = a.d_n1; }
         else { qset = 1; qprob = prob - 1; nqb = a.n2; qcount = a.d_n2 ? a.d_n2 + (prob - 1) : nullptr; }
+    } else if (a.pairs) {
+        qset = 1; qprob = a.pairs[2 * prob]; tprob = a.pairs[2 * prob + 1]; nqb = a.n2; qcount = tcount = nullptr;
     }
     const int nq_bound = a.has_ids ? a.n_ids : nqb;
     if (qtile * kWmQueries >= nq_bound || a.n2 <= 0) return;      // (no workgroup barrier below: the waves are on their own)
 
     // the descriptors stay where the caller holds them and are fetched through the index words
     const uint4* const qd = reinterpret_cast<const uint4*>(qset == 0 ? a.qdesc : a.tdesc) +
-                            (a.chain ? (size_t)qprob * a.cap2 : (size_t)qprob * a.cap1) * 2;
+                            (qset == 1 || a.chain ? (size_t)qprob * a.cap2 : (size_t)qprob * a.cap1) * 2;
     const float2* const qxy = a.sxy[qset] + (size_t)qprob * a.scap[qset];
     const uint32_t* const qidx = a.sidx[qset] + (size_t)qprob * a.scap[qset];
-    const uint4* const td = reinterpret_cast<const uint4*>(a.tdesc) + (size_t)prob * a.cap2 * 2;
-    const unsigned* const txy = reinterpret_cast<const unsigned*>(a.sxy[1] + (size_t)prob * a.scap[1]);
-    const uint32_t* const tidx = a.sidx[1] + (size_t)prob * a.scap[1];
-    const float4* const tbox = a.tile_box + (size_t)prob * (a.scap[1] / kMmSub);
+    const uint4* const td = reinterpret_cast<const uint4*>(a.tdesc) + (size_t)tprob * a.cap2 * 2;
+    const unsigned* const txy = reinterpret_cast<const unsigned*>(a.sxy[1] + (size_t)tprob * a.scap[1]);
+    const uint32_t* const tidx = a.sidx[1] + (size_t)tprob * a.scap[1];
+    const float4* const tbox = a.tile_box + (size_t)tprob * (a.scap[1] / kMmSub);
 
     // ---- first round of loads, all by the host's bounds (the counts in device memory are among them): the queries'
     //      index words and positions, the boxes of the train blocks.  What lies between a count and its bound has
@@ -777,7 +780,7 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
             bb[g] = tbox[min((g * 64 + lane) * a.splits + split, nblocks_bound - 1)];      // x min, x max, y min, y max
     int n1 = nqb, nt = a.n2;
     if (qcount) n1 = min(n1, *qcount);
-    if (a.d_n2) nt = min(nt, a.d_n2[prob]);
+    if (tcount) nt = min(nt, *tcount);
     const int nq = a.has_ids ? a.n_ids : n1;
 
     // ---- second round: the queries' descriptors.  Both lane halves hold the same 32 queries per block, half h 16
@@ -1020,7 +1023,13 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
         }
         if (h != 0 || !qvalid[b]) continue;
         const unsigned key = final_key(m);
-        if (key != kMmNoMatch) atomicMin(&a.best[out], key);
+        if (a.pairs) {
+            const unsigned d = key >> kMmIdxBits;
+            a.pair_out[(size_t)prob * a.n2 + qword[b]] =
+                (key != kMmNoMatch && (int)d <= a.dmax) ? ((d << 16) | (key & ((1u << kMmIdxBits) - 1u))) : kMmNoMatch;
+        } else if (key != kMmNoMatch) {
+            atomicMin(&a.best[out], key);
+        }
     }
 }
 
@@ -1039,7 +1048,7 @@ int window_mfma_splits(int batch, int nq_bound, int nt_bound, int n_cu) {
 }
 
 int launch_match_window_mfma(const WindowMatchArgs& a, int batch, int nq_bound, hipStream_t st) {
-    if (a.n2 > kWmMaxTrain || !(a.area > 0.f) || a.splits < 1)
+    if (a.n2 > kWmMaxTrain || !(a.area > 0.f) || a.splits < 1 || (a.pairs && (a.splits != 1 || a.part)))
         SA_FAIL(SLAM_AMD_ERR_ARG, "match: the reordered matrix-core kernel takes a window and at most 8192 train rows");
     const long long waves = (long long)div_up(nq_bound, kWmQueries) * a.splits * batch;
     const long long blocks = (waves + kWmWaves - 1) / kWmWaves;

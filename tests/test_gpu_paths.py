@@ -386,15 +386,18 @@ def test_match_pairs_vs_oracle(oracle, capi):
     d_pairs = torch.from_numpy(plist).cuda()
     out = torch.zeros((len(plist), n_per), dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    for area, lvl, md in ((-1.0, -1, 300.0), (-1.0, 4, 300.0), (150.0, 4, 300.0), (-1.0, -1, 100.0), (150.0, -1, 300.0)):
+    for area, lvl, md in ((-1.0, -1, 300.0), (-1.0, 4, 300.0), (150.0, 4, 300.0), (-1.0, -1, 100.0), (150.0, -1, 300.0),
+                          (40.0, 4, 300.0), (40.0, 3, 60.0)):
         ref = _pairs_reference(oracle, desc, kp, n_per, plist.tolist(), area, lvl, md)
-        for kernel in (0, 1):                # matrix cores, popcount
+        # matrix cores (with a window: keyframes reordered by grid cell, then as they are), popcount
+        for kernel, mode in ((0, 0), (0, 1), (1, 0)):
             m.debug_set_sweep_kernel(kernel)
+            m.debug_set_window_mode(mode)
             out.zero_()
             m.match_pairs_async(d_desc, d_kp, n_kf, n_per, d_pairs, len(plist), out, md, area, lvl, st)
             torch.cuda.synchronize()
             got = out.cpu().numpy().view(np.uint32)
-            assert np.array_equal(got, ref), (area, lvl, kernel)
+            assert np.array_equal(got, ref), (area, lvl, kernel, mode)
     m.close()
 
 
