@@ -67,6 +67,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // One descriptor dword -> the 32 nibbles of its bits (one product's operand of one lane): nibble j of output
 // dword k is bit k + 4 j of the input, one shift and one mask per output dword.  Train: 0b0001 = 0.5 where the
@@ -674,6 +675,9 @@ extern "C" int slam_amd_debug_mm_stamps(unsigned long long* out, int n_waves) {
 #ifndef SA_WM_NB
 #define SA_WM_NB 1
 #endif
+#ifndef SA_WM_SKIP
+#define SA_WM_SKIP 0      // timing experiments (wrong results): 1 no gates, 2 no products, 4 empty block lists, 8 no minimum
+#endif
 constexpr int kWmWaves = SA_WM_WAVES;         // waves per workgroup (they share nothing)
 constexpr int kWmNB = SA_WM_NB;               // query blocks of 32 per wave
 constexpr int kWmQueries = 32 * kWmNB;        // queries per wave
@@ -719,10 +723,11 @@ __device__ __forceinline__ float half_reduce(float v) {
 
 template <bool LEVEL, bool SECOND>
 __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(WindowMatchArgs a) {
-    __shared__ uint4 s_rows[kWmWaves][2][kMmSubU4];                       // a block's expanded rows, two deep per wave
-    __shared__ __align__(16) float s_pos[kWmWaves][2][3][kMmSub];         // its rows' x, y and accumulator operand
+    __shared__ __align__(16) float s_pos[kWmWaves][2][3][kMmSub];         // its rows' (x, y) pairs (2 x 32 floats) and accumulator operands
     __shared__ unsigned short s_list[kWmWaves][kWmMaxTrain / kMmSub];     // the train blocks a wave works on
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave's number as a scalar: everything derived from it -- problem, query tile, split -- then stays in scalar
+    // registers, divisions included)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 31, h = lane >> 5;
 #ifdef SA_WM_STAMPS
     const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
@@ -730,11 +735,11 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
 #endif
     // waves in the order (query tile, problem, split of the train blocks), the split fastest: the waves of a workgroup
     // share their queries when there are splits, and finish together
-    const long long wid = (long long)blockIdx.x * kWmWaves + wave;
-    const int split = (int)(wid % a.splits);
-    const long long rest = wid / a.splits;
-    const int prob = (int)(rest % a.batch);
-    const int qtile = (int)(rest / a.batch);
+    const unsigned wid = blockIdx.x * (unsigned)kWmWaves + (unsigned)wave;
+    const int split = (int)(wid % (unsigned)a.splits);
+    const unsigned rest = wid / (unsigned)a.splits;
+    const int prob = (int)(rest % (unsigned)a.batch);
+    const int qtile = (int)(rest / (unsigned)a.batch);
 
     // the query side: the problem's own rows of set 0, or, in a chained batch, the frame before (set 0 holds the one
     // before the batch)
@@ -847,21 +852,27 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // entry i of the list (-1 past its end), the same in every lane
+    if (SA_WM_SKIP & 4) n_live = 0;
     auto block_at = [&](int i) { return i < n_live ? __builtin_amdgcn_readfirstlane((int)s_list[wave][i]) : -1; };
 
-    struct Fetched { uint4 rows; unsigned pos, word; };
-    // lane (r, h), in two steps: the x (h = 0) or y of the block's row r and its index word, then dwords 4 h .. 4 h + 3
-    // of the row that the word names.  Rows past the end of the set repeat the last one; their position becomes
-    // +infinity, which fails the window with every query
+    struct Fetched { uint4 lo, hi; unsigned pos, word; };
+    // lane (r, h), in two steps: the x (h = 0) or y of the block's row r and its index word, then the row that the
+    // word names (all of it in either half: product s takes dword 2 s + h, picked below -- the operand of a product is
+    // this lane's own row, so the rows never pass through LDS).  Rows past the end of the set repeat the last one;
+    // their position becomes +infinity, which fails the window with every query
     auto fetch_meta = [&](int blk, Fetched& f) {
         const unsigned t = min((unsigned)(blk * kMmSub + r), (unsigned)(nt - 1));
         f.pos = txy[2 * t + h];
         f.word = tidx[t];
     };
-    auto fetch_rows = [&](Fetched& f) { f.rows = td[2 * (f.word & (unsigned)(kWmMaxTrain - 1)) + h]; };
+    auto fetch_rows = [&](Fetched& f) {
+        const unsigned t = f.word & (unsigned)(kWmMaxTrain - 1);
+        f.lo = td[2 * t];
+        f.hi = td[2 * t + 1];
+    };
     // two blocks ahead: the index words of the block after the next are on their way while the next one's rows are
     Fetched f, fn;
-    f.rows = make_uint4(0u, 0u, 0u, 0u);
+    f.lo = f.hi = make_uint4(0u, 0u, 0u, 0u);
     int at = 2;
     int blk = block_at(0), blk_n = block_at(1);
     if (blk >= 0) fetch_meta(blk, f);
@@ -885,17 +896,11 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
     }
     if (blk >= 0) fetch_rows(f);
 
-    // into LDS slice p: expanded rows as [step][half][row] of 16 bytes (dword d belongs to step d / 2, half d % 2),
-    // positions, accumulator operands 2^15 + 32 * 256 + index / 256 (exact in a float); returns the mask of rows
-    // above max_level
+    // into LDS slice p, for the lanes that hold the accumulators of other rows: positions, accumulator operands
+    // 2^15 + 32 * 256 + index / 256 (exact in a float); returns the mask of rows above max_level
     auto stage = [&](int p, const Fetched& f, int rows_left) {
-        uint4* const dst = s_rows[wave][p];
-        dst[(4 * h) * 32 + r] = expand_train(f.rows.x);
-        dst[(4 * h + 1) * 32 + r] = expand_train(f.rows.y);
-        dst[(4 * h + 2) * 32 + r] = expand_train(f.rows.z);
-        dst[(4 * h + 3) * 32 + r] = expand_train(f.rows.w);
         const bool odd = (f.pos & 0x7f800000u) == 0x7f800000u || r >= rows_left;
-        s_pos[wave][p][h][r] = __uint_as_float(odd ? 0x7f800000u : f.pos);
+        s_pos[wave][p][0][2 * r + h] = __uint_as_float(odd ? 0x7f800000u : f.pos);      // (x, y) of row r side by side
         if (h == 0) s_pos[wave][p][2][r] = (float)kMmBias + (float)(f.word & (unsigned)(kWmMaxTrain - 1)) * (1.f / 256.f);
         return LEVEL ? (unsigned)__ballot((f.word >> 31) != 0u) : 0u;
     };
@@ -922,6 +927,13 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
           stamp_wait += __builtin_amdgcn_s_memtime() - ta; }
 #endif
         const unsigned high = stage(p, f, nt - blk * kMmSub);
+        v4i af[kMmSteps];
+        {
+            const uint4 e0 = expand_train(h ? f.lo.y : f.lo.x), e1 = expand_train(h ? f.lo.w : f.lo.z);
+            const uint4 e2 = expand_train(h ? f.hi.y : f.hi.x), e3 = expand_train(h ? f.hi.w : f.hi.z);
+            af[0] = v4i{(int)e0.x, (int)e0.y, (int)e0.z, (int)e0.w}; af[1] = v4i{(int)e1.x, (int)e1.y, (int)e1.z, (int)e1.w};
+            af[2] = v4i{(int)e2.x, (int)e2.y, (int)e2.z, (int)e2.w}; af[3] = v4i{(int)e3.x, (int)e3.y, (int)e3.z, (int)e3.w};
+        }
         blk = blk_n;
         f.pos = fn.pos; f.word = fn.word;
         blk_n = block_at(at++);
@@ -940,11 +952,12 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
                 cin[4 * j] = v.x; cin[4 * j + 1] = v.y; cin[4 * j + 2] = v.z; cin[4 * j + 3] = v.w;
             }
 #pragma unroll
-            for (int s = 0; s < kMmSteps; s++) {
-                const v4i af = *reinterpret_cast<const v4i*>(&s_rows[wave][p][s * 64 + h * 32 + r]);
+            for (int s = 0; s < kMmSteps; s++)
 #pragma unroll
-                for (int b = 0; b < kWmNB; b++) acc[b] = product(af, bq[b][s], s == 0 ? cin : acc[b], scale_a, scale_b);
-            }
+                for (int b = 0; b < kWmNB; b++) {
+                    if (SA_WM_SKIP & 2) { if (s == 0) acc[b] = cin; else acc[b][s] += __int_as_float(af[s].x ^ bq[b][s].y); }
+                    else acc[b] = product(af[s], bq[b][s], s == 0 ? cin : acc[b], scale_a, scale_b);
+                }
         }
         // ---- gates, as in match_mfma_kernel: the sign of (bits(area) - 1) - bits(max(|dx|, |dy|)) is "not inside
         //      the window"; bit `row` of the block's mask of high rows for queries that are high themselves ----
@@ -955,27 +968,33 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
             for (int b = 0; b < kWmNB; b++) mine[b] = (kLevelOn && qhigh[b]) ? high >> (4 * h) : 0u;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const v4f x4 = *reinterpret_cast<const v4f*>(&s_pos[wave][p][0][8 * j + 4 * h]);
-                const v4f y4 = *reinterpret_cast<const v4f*>(&s_pos[wave][p][1][8 * j + 4 * h]);
+                // rows 8 j + 4 h .. + 3 as (x, y) pairs: one packed subtraction per pair of a query and a train row
+                const v4f xy01 = *reinterpret_cast<const v4f*>(&s_pos[wave][p][0][2 * (8 * j + 4 * h)]);
+                const v4f xy23 = *reinterpret_cast<const v4f*>(&s_pos[wave][p][0][2 * (8 * j + 4 * h) + 4]);
+                const v2f txy4[4] = {{xy01.x, xy01.y}, {xy01.z, xy01.w}, {xy23.x, xy23.y}, {xy23.z, xy23.w}};
 #pragma unroll
                 for (int b = 0; b < kWmNB; b++)
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
                         const int i = 4 * j + c;
-                        const float dx = qx[b] - x4[c], dy = qy[b] - y4[c];
-                        unsigned sign = (unsigned)(area_bits_m1 - (int)__float_as_uint(fmaxf(fabsf(dx), fabsf(dy))));
+                        const v2f qv = {qx[b], qy[b]};
+                        const v2f d = qv - txy4[c];
+                        unsigned sign = (unsigned)(area_bits_m1 - (int)__float_as_uint(fmaxf(fabsf(d.x), fabsf(d.y))));
                         if (kLevelOn) sign |= mine[b] << (31 - acc_row(i, 0));
                         const float v = acc[b][i];
                         acc[b][i] = __uint_as_float((sign & kMmFail) | __float_as_uint(v));
                     }
             }
         };
-        if (LEVEL && high != 0u && any_qhigh) gates(std::true_type());
+        if (SA_WM_SKIP & 1) { }
+        else if (LEVEL && high != 0u && any_qhigh) gates(std::true_type());
         else gates(std::false_type());
         // ---- the block's minimum (two smallest with SECOND) into the running one ----
 #pragma unroll
         for (int b = 0; b < kWmNB; b++) {
-            if (!SECOND) {
+            if (SA_WM_SKIP & 8) {
+                best[b] = min(best[b], acc_bits(acc[b], 0) + acc_bits(acc[b], 5) + acc_bits(acc[b], 10) + acc_bits(acc[b], 15));
+            } else if (!SECOND) {
                 unsigned m = best[b];
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) m = min(min(m, acc_bits(acc[b], i)), acc_bits(acc[b], i + 1));
@@ -1053,7 +1072,7 @@ int launch_match_window_mfma(const WindowMatchArgs& a, int batch, int nq_bound, 
     const long long waves = (long long)div_up(nq_bound, kWmQueries) * a.splits * batch;
     const long long blocks = (waves + kWmWaves - 1) / kWmWaves;
     if (blocks <= 0) return SLAM_AMD_OK;
-    if (blocks > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match: problem too large for one launch");
+    if (waves + kWmWaves > 0x7fffffffLL) SA_FAIL(SLAM_AMD_ERR_ARG, "match: problem too large for one launch");
     const dim3 grid((unsigned)blocks), block(kWmWaves * 64);
     const bool level = a.max_level != -1, second = a.part != nullptr;
     if (level && second) hipLaunchKernelGGL((match_window_mfma_kernel<true, true>), grid, block, 0, st, a);

@@ -14,8 +14,8 @@ for p in ("a", "b"):
     for f in glob.glob(out + "/" + p + "/**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            if "match_mfma" in r["Kernel_Name"]:
-                agg[r["Kernel_Name"].split("match_mfma_kernel")[1][:28]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if "match_mfma" in r["Kernel_Name"] or "match_window_mfma" in r["Kernel_Name"]:
+                agg[r["Kernel_Name"].split("sa::")[1][:52]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in sorted(agg.items()):
             print(k, " ".join("%s=%.0f" % (c.replace("SQ_", ""), sum(x) / len(x)) for c, x in sorted(v.items())))
 PY
