@@ -170,9 +170,9 @@ int slam_amd_extractor_debug_set_select_cache(slam_amd_extractor* ex, int entrie
 int slam_amd_matcher_create(int device, slam_amd_matcher** out);
 int slam_amd_matcher_destroy(slam_amd_matcher* m);
 /* Sizes the matcher's device scratch for calls of at most `batch` problems of at most
- * `query_rows` x `train_rows` rows each (train_rows may be 0 when the window-gated,
- * cell-sorted path will not be used): 4 bytes per query row, 128 more while the ratio
- * option is set, 44 per row of both sets for the cell-sorted path.  Later _async calls
+ * `query_rows` x `train_rows` rows each (train_rows may be 0 when no call will have the
+ * window gate on): 4 bytes per query row, 128 more while the ratio option is set, 44.5 per
+ * row of both sets for the reordered copies of window-gated calls.  Later _async calls
  * within these sizes allocate nothing.
  * Rule for HIP graphs: an _async call issued while its stream is capturing never
  * allocates -- if the scratch is too small it returns SLAM_AMD_ERR_CAPACITY -- and once a
@@ -197,10 +197,14 @@ int slam_amd_matcher_reserve(slam_amd_matcher* m, int batch, int query_rows, int
  * slam_amd_match_pairs_async returns SLAM_AMD_ERR_UNSUPPORTED while either is set. */
 int slam_amd_matcher_set_options(slam_amd_matcher* m, float ratio, int histo_length);
 
-/* Test hook.  With the window gate on (area != -1) large problems are matched after
- * reordering both sets by grid cell, visiting only train tiles near each group of
- * queries; the result is identical to the full sweep.  mode 0 chooses by size
- * (queries x train rows >= 2^30), 1 forces the full sweep, 2 forces the cell-sorted path. */
+/* Test hook.  With the window gate on (area > 0) both sets are first reordered by grid
+ * cell (index words and positions in the matcher's scratch), and every group of neighbouring
+ * queries is matched only against the blocks of train rows that lie within the window of
+ * it; the result is identical to the full sweep.  mode 0 (default): train sets of up to
+ * 8192 rows go through the matrix-core kernel for reordered sets, larger ones through the
+ * popcount kernel for reordered sets once queries x train rows >= 2^30, the rest through the
+ * full sweep; 1 forces the full sweep; 2 forces the popcount kernel on reordered sets; 3 the
+ * matrix-core kernel on reordered sets (where the train set fits, else as 0). */
 int slam_amd_matcher_debug_set_window_mode(slam_amd_matcher* m, int mode);
 
 /* Test hook.  The full sweep (every query against every train row) forms its distances on the
@@ -248,7 +252,7 @@ int slam_amd_frame_match_async(slam_amd_matcher* m,
  * -- the running best keys, and the (best, second) planes while the ratio option is set --
  * is a fixed array inside the library's code object (4.1 MiB per GPU, held until the process
  * ends) instead of buffers the matcher allocates.  It calls no hipMalloc / hipFree, and always
- * uses the full sweep (never the cell-sorted window path, which needs reordered copies).
+ * uses the full sweep (never the window paths over reordered sets, which need scratch for them).
  * At most SLAM_AMD_NOALLOC_MAX_QUERIES query rows (max(n1, n_ids)); more is
  * SLAM_AMD_ERR_CAPACITY.  All calls on one GPU share that GPU's array: calls that overlap in
  * time on one GPU (different streams, different matchers) race; serialise them. */
@@ -281,8 +285,9 @@ int slam_amd_frame_match_batch_async(slam_amd_matcher* m, int batch,
  * d_prev_* (the last frame of the batch before; d_prev_n points to its count).  This is the
  * reference's frame-against-the-one-before matching (Matcher::frameMatch(initial, current),
  * src/tracking/mapper.cpp:34; last key frame against the current frame, src/tracking/tracker.cpp:74)
- * over a batch of consecutive frames.  The window gate runs as a full sweep here.  Results as
- * slam_amd_frame_match_batch_async: d_out[b*cap + i], d_n_out[b]. */
+ * over a batch of consecutive frames.  With the window gate on, every frame is reordered by grid
+ * cell once and serves as the train set of its own problem and the query set of the next.
+ * Results as slam_amd_frame_match_batch_async: d_out[b*cap + i], d_n_out[b]. */
 int slam_amd_frame_match_chain_async(slam_amd_matcher* m, int batch,
                                      const uint8_t* d_prev_desc, const slam_amd_keypoint* d_prev_kp,
                                      const int32_t* d_prev_n,
@@ -297,7 +302,10 @@ int slam_amd_frame_match_chain_async(slam_amd_matcher* m, int batch,
  * index pairs.  Output: one 32-bit word per query row of every pair,
  * (distance << 16) | trainIdx, or 0xFFFFFFFF when no train row passes.
  * n_per <= 65535.  This is frameMatch(kf_i, kf_j, {}, ...) for many pairs, the
- * all-defaults form of src/tracking/mapper.cpp:34. */
+ * all-defaults form of src/tracking/mapper.cpp:34.  With the window gate on and n_per <= 8192
+ * the keyframes are first reordered by grid cell in the matcher's scratch (44.5 bytes per
+ * row; allocated on the first such call, which therefore must not be under stream capture --
+ * or reserved with slam_amd_matcher_reserve(m, n_keyframes, 0, n_per)). */
 int slam_amd_match_pairs_async(slam_amd_matcher* m,
                                const uint8_t* d_desc, const slam_amd_keypoint* d_kp,
                                int n_keyframes, int n_per,

@@ -888,7 +888,7 @@ extern "C" int slam_amd_matcher_reserve(slam_amd_matcher* m, int batch, int quer
     int rc;
     if ((rc = grow_scratch(m, m->best, fill_bytes(rows * sizeof(unsigned)), false))) return rc;
     if (m->ratio > 0.f && (rc = grow_scratch(m, m->part, fill_bytes(rows * kMaxSecondSplits * sizeof(uint2)), false))) return rc;
-    if (train_rows > 0 && query_rows > 0 &&
+    if (train_rows > 0 &&
         (rc = grow_scratch(m, m->sorted, sorted_layout(batch, query_rows, train_rows).total, false))) return rc;
     return SLAM_AMD_OK;
 }
