@@ -309,6 +309,56 @@ def test_frame_match_chain(oracle, capi):
                 assert res[b * CAP: b * CAP + len(ref)].tobytes() == ref.tobytes(), (b, area, ratio)
 
 
+def test_windowed_chain_under_graph_capture(oracle, capi):
+    """The window-gated chained match (both sets reordered by grid cell in the matcher's scratch) recorded into a
+    graph: refused while the scratch is not reserved, and two replays over different inputs equal the oracle."""
+    torch = _torch()
+    B, CAP = 3, 640
+    counts = [600, 640, 333]
+    def load(seed):
+        sets = [_sets(CAP, CAP, seed + b) for b in range(B + 1)]
+        d = np.concatenate([sets[b][0] for b in range(B)]); k = np.concatenate([sets[b][1] for b in range(B)])
+        return sets, torch.from_numpy(d).cuda(), _dev_kp(torch, k), torch.from_numpy(sets[B][0]).cuda(), _dev_kp(torch, sets[B][1])
+    sets, D, K, Dp, Kp = load(300)
+    N = torch.tensor(counts, dtype=torch.int32, device="cuda"); Np = torch.tensor([500], dtype=torch.int32, device="cuda")
+    out = torch.zeros(B * CAP * DM, dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(B, dtype=torch.int32, device="cuda")
+    m = capi.Matcher()
+    m.reserve(B, CAP, 0)            # keys only: nothing for the reordered sets
+    g = torch.cuda.CUDAGraph()
+    refused = False
+    try:
+        with torch.cuda.graph(g):
+            m.frame_match_chain_async(B, Dp, Kp, Np, D, K, CAP, N, out, nout, 300.0, 60.0, 4,
+                                      torch.cuda.current_stream().cuda_stream)
+    except capi.SlamAmdError:
+        refused = True
+    assert refused
+    del g
+    m.close()
+    m = capi.Matcher()
+    m.reserve(B, CAP, CAP)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        m.frame_match_chain_async(B, Dp, Kp, Np, D, K, CAP, N, out, nout, 300.0, 60.0, 4,
+                                  torch.cuda.current_stream().cuda_stream)
+    for seed in (300, 400):
+        if seed != 300:
+            sets, D2, K2, Dp2, Kp2 = load(seed)
+            D.copy_(D2); K.copy_(K2); Dp.copy_(Dp2); Kp.copy_(Kp2)
+        out.zero_(); nout.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().view(capi.DMATCH_DTYPE)
+        for b in range(B):
+            d1, k1 = (sets[B][0][:500], sets[B][1][:500]) if b == 0 else (sets[b - 1][0][:counts[b - 1]], sets[b - 1][1][:counts[b - 1]])
+            ref = oracle.match_gated(d1, k1, sets[b][0][:counts[b]], sets[b][1][:counts[b]], 300.0, 60.0, 4)
+            assert int(nout[b].item()) == len(ref), (seed, b)
+            assert res[b * CAP: b * CAP + len(ref)].tobytes() == ref.tobytes(), (seed, b)
+    del g
+    m.close()
+
+
 def test_frame_match_async_and_batch(oracle, capi):
     torch = _torch()
     st = torch.cuda.current_stream().cuda_stream
