@@ -655,13 +655,18 @@ extern "C" int slam_amd_debug_mm_stamps(unsigned long long* out, int n_waves) {
 // Window-gated matching of sets reordered by grid cell, wave by wave.
 //
 // With the window gate on, a query can only match train rows within `area` of it.  spatial_sort_kernel has put both
-// sets in grid-cell order, so that 64 consecutive queries and 32 consecutive train rows each cover a small patch of
-// the image, and has left the bounding box of every block of 32 train rows.  A wave takes 64 queries (two blocks of
-// 32, expanded once into registers) and first tests every train block's box against its own: the blocks that lie a
-// window or more away -- most of them -- are never fetched.  The others it fetches, expands into its own slice of
-// LDS and multiplies exactly as match_mfma_kernel does (same operands, same accumulator encoding, the same gates on
-// the accumulators); no barrier, no work shared with the other waves of the workgroup, so a wave's time follows
-// its own list of blocks and not the longest list among its neighbours.
+// sets in grid-cell order -- index words (original index | octave-above-max_level flag) and positions; the
+// descriptors stay where the caller holds them -- so that 32 consecutive queries and 32 consecutive train rows each
+// cover a small patch of the image, and has left the bounding box of every block of 32 train rows.  A wave takes 32
+// queries (expanded once into registers) and first tests every train block's box against its own, one box per lane:
+// the blocks that lie a window or more away -- four in five at a 50-pixel window on 640 x 480 -- are never fetched.
+// The others it works through one by one: lane (r, h) fetches the block's row r through its index word (two blocks
+// ahead of its use) and expands the dwords its lane half supplies in registers -- the operand of a product is the
+// lane's own train row, so the rows never pass through LDS --, then the same four products, accumulator encoding
+// and gates as in match_mfma_kernel.  Only the positions and accumulator operands of the block's rows go through a
+// wave-private slice of LDS (an accumulator register belongs to another lane's train row).  No barrier, nothing
+// shared with the other waves of the workgroup: a wave's time follows its own list of blocks, not the longest
+// list among its neighbours (the tiled kernel fed with reordered sets lost most of the gain to that).
 //
 // A row's place in the reordered set says nothing about which row it was, and ties must go to the lowest original
 // train index: the accumulator operand of a block's first product carries the row's original index (13 bits: the 5

@@ -1,12 +1,16 @@
-// Window-gated matching without the full Nq x Nt sweep.
+// Window-gated matching without the full Nq x Nt sweep: the reordering of both sets by grid cell
+// (spatial_sort_kernel, which serves both window kernels) and the popcount window kernel.
 //
 // With the window gate on (|dx| < area and |dy| < area, src/frame/matcher.cpp:148-153)
 // only train rows near a query can win.  Both sets are first reordered by grid cell
-// (cell edge >= area), 64 rows to a tile, and every tile gets its bounding box.  A
-// wave of 64 spatially close queries then visits only the train tiles whose box lies
-// within `area` of the wave's own box; inside a visited tile every row is still put
-// through the exact gate and distance of the brute-force kernel, and the key carries
-// the row's original index, so the result is bit-identical to the full sweep.
+// (cell edge >= area): index word (original index | octave-above-max_level flag) and position
+// per row, a bounding box per tile of 32 or 64 train rows, and for the popcount kernel a copy of
+// the descriptors.  The popcount kernel (match_window_kernel, train sets beyond what the
+// matrix-core kernel of match_mfma_kernels.hip indexes): a wave of 64 spatially close queries
+// visits only the train tiles whose box lies within `area` of the wave's own box; inside a
+// visited tile every row is still put through the exact gate and distance of the brute-force
+// kernel, and the key carries the row's original index, so the result is bit-identical to the
+// full sweep.
 #include <math.h>
 
 #include <algorithm>
