@@ -359,6 +359,50 @@ def test_windowed_chain_under_graph_capture(oracle, capi):
     m.close()
 
 
+def test_windowed_chain_on_extracted_frames_all_paths_agree(oracle, capi):
+    """Benchmark-shaped input (640 x 480 frames through the extractor, ~2000 keypoints each, clustered as real corners
+    are): the chained match with the window and octave gates through the reordered matrix-core path, the gated full
+    sweep and the popcount kernel gives the same bytes; one frame pair is also checked against the oracle."""
+    torch = _torch()
+    st = torch.cuda.current_stream().cuda_stream
+    W, H, B, CAP = 640, 480, 12, 4096
+    ex = capi.Extractor(capi.orb_params(nfeatures=2000), W, H, max_batch=B, max_keypoints=CAP)
+    frames = synth.frame_sequence(W, H, B, seed=21)
+    d_img = torch.from_numpy(np.stack(frames)).cuda()
+    kp = torch.zeros(B * CAP * KP, dtype=torch.uint8, device="cuda")
+    desc = torch.zeros(B * CAP * 32, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.extract_batch_async(d_img, B, H * W, W, kp.data_ptr(), desc.data_ptr(), cnt.data_ptr(), CAP, st)
+    torch.cuda.synchronize()
+    counts = cnt.cpu().numpy()
+    assert counts.min() > 1500
+    m = capi.Matcher()
+    m.reserve(B, CAP, CAP)
+    out = torch.zeros(B * CAP * DM, dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(B, dtype=torch.int32, device="cuda")
+    last = B - 1
+    results = {}
+    for area, lvl in ((50.0, 4), (20.0, -1), (120.0, 2)):
+        for name, kernel, mode in (("reordered", 0, 3), ("full sweep", 0, 1), ("popcount", 1, 1)):
+            m.debug_set_sweep_kernel(kernel)
+            m.debug_set_window_mode(mode)
+            out.zero_(); nout.zero_()
+            m.frame_match_chain_async(B, desc.data_ptr() + last * CAP * 32, kp.data_ptr() + last * CAP * KP, cnt.data_ptr() + 4 * last,
+                                      desc.data_ptr(), kp.data_ptr(), CAP, cnt.data_ptr(), out, nout, 300.0, area, lvl, st)
+            torch.cuda.synchronize()
+            results[name] = (out.cpu().numpy().copy(), nout.cpu().numpy().copy())
+        for name in ("full sweep", "popcount"):
+            assert np.array_equal(results["reordered"][1], results[name][1]), (area, lvl, name)
+            assert results["reordered"][0].tobytes() == results[name][0].tobytes(), (area, lvl, name)
+        assert results["reordered"][1].min() > 200, (area, lvl)
+        # frame 5 against frame 4 on the CPU
+        k_all = kp.cpu().numpy().view(capi.KEYPOINT_DTYPE).reshape(B, CAP); d_all = desc.cpu().numpy().reshape(B, CAP, 32)
+        ref = oracle.match_gated(d_all[4][:counts[4]], k_all[4][:counts[4]], d_all[5][:counts[5]], k_all[5][:counts[5]], 300.0, area, lvl)
+        got = results["reordered"][0].view(capi.DMATCH_DTYPE)[5 * CAP: 5 * CAP + len(ref)]
+        assert int(results["reordered"][1][5]) == len(ref) and got.tobytes() == ref.tobytes(), (area, lvl)
+    m.close(); ex.close()
+
+
 def test_frame_match_async_and_batch(oracle, capi):
     torch = _torch()
     st = torch.cuda.current_stream().cuda_stream
