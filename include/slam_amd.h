@@ -201,7 +201,7 @@ int slam_amd_matcher_set_options(slam_amd_matcher* m, float ratio, int histo_len
  * cell (index words and positions in the matcher's scratch), and every group of neighbouring
  * queries is matched only against the blocks of train rows that lie within the window of
  * it; the result is identical to the full sweep.  mode 0 (default): train sets of up to
- * 8192 rows go through the matrix-core kernel for reordered sets, larger ones through the
+ * 32768 rows go through the matrix-core kernel for reordered sets, larger ones through the
  * popcount kernel for reordered sets once queries x train rows >= 2^30, the rest through the
  * full sweep; 1 forces the full sweep; 2 forces the popcount kernel on reordered sets; 3 the
  * matrix-core kernel on reordered sets (where the train set fits, else as 0). */
@@ -302,7 +302,7 @@ int slam_amd_frame_match_chain_async(slam_amd_matcher* m, int batch,
  * index pairs.  Output: one 32-bit word per query row of every pair,
  * (distance << 16) | trainIdx, or 0xFFFFFFFF when no train row passes.
  * n_per <= 65535.  This is frameMatch(kf_i, kf_j, {}, ...) for many pairs, the
- * all-defaults form of src/tracking/mapper.cpp:34.  With the window gate on and n_per <= 8192
+ * all-defaults form of src/tracking/mapper.cpp:34.  With the window gate on and n_per <= 32768
  * the keyframes are first reordered by grid cell in the matcher's scratch (44.5 bytes per
  * row; allocated on the first such call, which therefore must not be under stream capture --
  * or reserved with slam_amd_matcher_reserve(m, n_keyframes, 0, n_per)). */

@@ -672,7 +672,10 @@ extern "C" int slam_amd_debug_mm_stamps(unsigned long long* out, int n_waves) {
 // train index: the accumulator operand of a block's first product carries the row's original index (13 bits: the 5
 // bits that hold the row inside its block in match_mfma_kernel plus the 8 fraction bits that a float in
 // [2^15, 2^16) has left), so the bit patterns order like (distance, original index) across all blocks and the
-// running minimum is a plain unsigned minimum.  Train sets of up to 2^13 rows.
+// running minimum is a plain unsigned minimum.  Larger train sets: the reordering works inside chunks of 4096
+// consecutive rows, so a block's rows all come from the same aligned group of 2^13 original indices; the accumulators
+// carry the index inside the group, and a block's minimum gets its group's base added before it meets the running
+// one (full keys, distance << 20 | original index).  Up to 2^15 train rows (the length of a wave's block list).
 // =============================================================================
 #ifndef SA_WM_WAVES
 #define SA_WM_WAVES 4
@@ -686,9 +689,9 @@ extern "C" int slam_amd_debug_mm_stamps(unsigned long long* out, int n_waves) {
 constexpr int kWmWaves = SA_WM_WAVES;         // waves per workgroup (they share nothing)
 constexpr int kWmNB = SA_WM_NB;               // query blocks of 32 per wave
 constexpr int kWmQueries = 32 * kWmNB;        // queries per wave
-constexpr int kWmIdxBits = 13;
-constexpr int kWmMaxTrain = 1 << kWmIdxBits;
-constexpr int kWmGroups = kWmMaxTrain / kMmSub / 64;      // groups of 64 train blocks (one box test per lane)
+constexpr int kWmIdxBits = 13;                // index bits an accumulator carries: a row's original index inside its group of 2^13
+constexpr int kWmIdxGroup = 1 << kWmIdxBits;
+constexpr int kWmMaxTrain = 1 << 15;          // train rows per problem (a wave's block list holds 1024 entries)
 
 #ifdef SA_WM_STAMPS
 // Diagnostic build only, per wave: shader clock at the start, at the first block and at the end, blocks worked on,
@@ -781,13 +784,10 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
         qword[b] = qidx[qc];
         qpos[b] = qxy[qc];
     }
-    // (lane l of group g looks at the block (64 g + l) * splits + split: this split's blocks only)
+    // (lane l of group g looks at the block (64 g + l) * splits + split: this split's blocks only; the first group's
+    // boxes here, the others' one group ahead in the loop below)
     const int nblocks_bound = (a.n2 + kMmSub - 1) / kMmSub;
-    float4 bb[kWmGroups];
-#pragma unroll
-    for (int g = 0; g < kWmGroups; g++)
-        if (g * 64 * a.splits < nblocks_bound)
-            bb[g] = tbox[min((g * 64 + lane) * a.splits + split, nblocks_bound - 1)];      // x min, x max, y min, y max
+    float4 bb = tbox[min(lane * a.splits + split, nblocks_bound - 1)];      // x min, x max, y min, y max
     int n1 = nqb, nt = a.n2;
     if (qcount) n1 = min(n1, *qcount);
     if (tcount) nt = min(nt, *tcount);
@@ -834,16 +834,18 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
     qbox[2] = half_reduce<false>(qbox[2]); qbox[3] = half_reduce<true>(qbox[3]);
     const int nblocks = (nt + kMmSub - 1) / kMmSub;
     int n_live = 0;      // the list goes through LDS: walking bit masks costs more instructions than the list has entries
-#pragma unroll
-    for (int g = 0; g < kWmGroups; g++) {
-        if (g * 64 * a.splits >= nblocks_bound) continue;
+    const int ngroups = ((nblocks - split + a.splits - 1) / a.splits + 63) >> 6;      // groups of 64 of this split's blocks
+    for (int g = 0; g < ngroups; g++) {
+        float4 nb = bb;
+        if (g + 1 < ngroups) nb = tbox[min(((g + 1) * 64 + lane) * a.splits + split, nblocks_bound - 1)];
         const int blk = (g * 64 + lane) * a.splits + split;
         const bool on = blk < nblocks &&
-                        !(bb[g].x - qbox[1] >= a.area || qbox[0] - bb[g].y >= a.area || bb[g].z - qbox[3] >= a.area || qbox[2] - bb[g].w >= a.area);
+                        !(bb.x - qbox[1] >= a.area || qbox[0] - bb.y >= a.area || bb.z - qbox[3] >= a.area || qbox[2] - bb.w >= a.area);
         const unsigned long long mask = __ballot(on);
         const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         if (on) s_list[wave][n_live + before] = (unsigned short)blk;
         n_live += __builtin_popcountll(mask);
+        bb = nb;
     }
 #ifdef SA_WM_COUNT
     if (lane == 0) {
@@ -871,7 +873,7 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
         f.word = tidx[t];
     };
     auto fetch_rows = [&](Fetched& f) {
-        const unsigned t = f.word & (unsigned)(kWmMaxTrain - 1);
+        const unsigned t = f.word & 0x7fffffffu;
         f.lo = td[2 * t];
         f.hi = td[2 * t + 1];
     };
@@ -906,7 +908,7 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
     auto stage = [&](int p, const Fetched& f, int rows_left) {
         const bool odd = (f.pos & 0x7f800000u) == 0x7f800000u || r >= rows_left;
         s_pos[wave][p][0][2 * r + h] = __uint_as_float(odd ? 0x7f800000u : f.pos);      // (x, y) of row r side by side
-        if (h == 0) s_pos[wave][p][2][r] = (float)kMmBias + (float)(f.word & (unsigned)(kWmMaxTrain - 1)) * (1.f / 256.f);
+        if (h == 0) s_pos[wave][p][2][r] = (float)kMmBias + (float)(f.word & (unsigned)(kWmIdxGroup - 1)) * (1.f / 256.f);
         return LEVEL ? (unsigned)__ballot((f.word >> 31) != 0u) : 0u;
     };
 
@@ -916,11 +918,13 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
     unsigned best[kWmNB], second[kWmNB];
 #pragma unroll
     for (int b = 0; b < kWmNB; b++) best[b] = second[b] = kMmNoMatch;
-    // pattern -> key Hb << 20 | original index (a pattern with the failure mark: Hb = 1023)
+    // pattern -> key Hb << 20 | index inside the group (a pattern with the failure mark: Hb = 1023)
     auto bits_key = [](unsigned bits) {
         const unsigned u = min(bits - kMmBinade, 0x7fffffu);
         return ((u & ~0x1fffu) << 7) + (u & 0x1fffu);
     };
+    // train sets of more than one index group: the running minimum is kept as full keys (see the head of the kernel)
+    const bool groups = a.n2 > kWmIdxGroup;
 
     int p = 0;
 #ifdef SA_WM_STAMPS
@@ -932,6 +936,7 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
           stamp_wait += __builtin_amdgcn_s_memtime() - ta; }
 #endif
         const unsigned high = stage(p, f, nt - blk * kMmSub);
+        const unsigned base = (unsigned)(blk * kMmSub) & ~(unsigned)(kWmIdxGroup - 1);      // of the block's index group
         v4i af[kMmSteps];
         {
             const uint4 e0 = expand_train(h ? f.lo.y : f.lo.x), e1 = expand_train(h ? f.lo.w : f.lo.z);
@@ -999,11 +1004,16 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
         for (int b = 0; b < kWmNB; b++) {
             if (SA_WM_SKIP & 8) {
                 best[b] = min(best[b], acc_bits(acc[b], 0) + acc_bits(acc[b], 5) + acc_bits(acc[b], 10) + acc_bits(acc[b], 15));
-            } else if (!SECOND) {
+            } else if (!SECOND && !groups) {
                 unsigned m = best[b];
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) m = min(min(m, acc_bits(acc[b], i)), acc_bits(acc[b], i + 1));
                 best[b] = m;
+            } else if (!SECOND) {
+                unsigned m = min(acc_bits(acc[b], 0), acc_bits(acc[b], 1));
+#pragma unroll
+                for (int i = 2; i < 16; i += 2) m = min(min(m, acc_bits(acc[b], i)), acc_bits(acc[b], i + 1));
+                best[b] = min(best[b], bits_key(m) + base);
             } else {
                 unsigned lo = kMmNoMatch, hi = kMmNoMatch;
 #pragma unroll
@@ -1013,7 +1023,7 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
                     hi = min(max(lo, l2), min(hi, h2));
                     lo = min(lo, l2);
                 }
-                const unsigned klo = bits_key(lo), khi = bits_key(hi);
+                const unsigned klo = bits_key(lo) + base, khi = bits_key(hi) + base;
                 second[b] = min(max(best[b], klo), min(second[b], khi));
                 best[b] = min(best[b], klo);
             }
@@ -1030,7 +1040,7 @@ __global__ __launch_bounds__(kWmWaves * 64) void match_window_mfma_kernel(Window
 
 #pragma unroll
     for (int b = 0; b < kWmNB; b++) {
-        const unsigned mine = SECOND ? best[b] : bits_key(best[b]);
+        const unsigned mine = (SECOND || groups) ? best[b] : bits_key(best[b]);
         const unsigned ob = (unsigned)__shfl_xor((int)mine, 32, 64);
         const unsigned m = min(mine, ob);
         // pairs that failed a gate and rows beyond the set carry distances above 256
@@ -1073,7 +1083,7 @@ int window_mfma_splits(int batch, int nq_bound, int nt_bound, int n_cu) {
 
 int launch_match_window_mfma(const WindowMatchArgs& a, int batch, int nq_bound, hipStream_t st) {
     if (a.n2 > kWmMaxTrain || !(a.area > 0.f) || a.splits < 1 || (a.pairs && (a.splits != 1 || a.part)))
-        SA_FAIL(SLAM_AMD_ERR_ARG, "match: the reordered matrix-core kernel takes a window and at most 8192 train rows");
+        SA_FAIL(SLAM_AMD_ERR_ARG, "match: the reordered matrix-core kernel takes a window and at most 32768 train rows");
     const long long waves = (long long)div_up(nq_bound, kWmQueries) * a.splits * batch;
     const long long blocks = (waves + kWmWaves - 1) / kWmWaves;
     if (blocks <= 0) return SLAM_AMD_OK;

@@ -135,7 +135,7 @@ def test_cell_sorted_window_match_equals_full_sweep(oracle, capi, nq, nt, area, 
     m.close()
 
 
-@pytest.mark.parametrize("nt", [2030, 8192, 700])
+@pytest.mark.parametrize("nt", [2030, 8192, 700, 12000, 32768])
 def test_cell_sorted_matrix_core_match_ties_and_options(oracle, capi, nt):
     """Reordered sets on the matrix cores: equal train rows at nearby positions (the lowest original index must
     win wherever the reordering puts the rows), the ratio test and the rotation check, ids and query positions."""
