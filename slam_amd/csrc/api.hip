@@ -1198,7 +1198,9 @@ extern "C" int slam_amd_match_pairs_async(slam_amd_matcher* m,
     // With the window gate on, the keyframes are first reordered by grid cell (index words and positions in the
     // matcher's scratch) and every pair goes through the kernel that only looks at the train blocks near a wave's
     // queries; same result.
-    if (m->sweep_kernel == 0 && m->window_mode != 1 && area > 0.f && area <= 3.0e38f && n_per <= window_mfma_max_train() && n_pairs > 0) {
+    // (every keyframe is reordered, whether a pair names it or not: not worth it for a few pairs of many keyframes)
+    if (m->sweep_kernel == 0 && m->window_mode != 1 && area > 0.f && area <= 3.0e38f && n_per <= window_mfma_max_train() &&
+        n_pairs > 0 && (m->window_mode == 3 || (long long)n_pairs * 8 >= n_keyframes)) {
         const SortedLayout lay = sorted_layout(n_keyframes, 0, n_per);
         int rc;
         if ((rc = grow_scratch(m, m->sorted, lay.total, stream_capturing(st)))) return rc;

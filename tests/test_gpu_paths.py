@@ -484,7 +484,7 @@ def test_match_pairs_vs_oracle(oracle, capi):
                           (40.0, 4, 300.0), (40.0, 3, 60.0)):
         ref = _pairs_reference(oracle, desc, kp, n_per, plist.tolist(), area, lvl, md)
         # matrix cores (with a window: keyframes reordered by grid cell, then as they are), popcount
-        for kernel, mode in ((0, 0), (0, 1), (1, 0)):
+        for kernel, mode in ((0, 0), (0, 3), (0, 1), (1, 0)):
             m.debug_set_sweep_kernel(kernel)
             m.debug_set_window_mode(mode)
             out.zero_()
