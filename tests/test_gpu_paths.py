@@ -403,6 +403,32 @@ def test_windowed_chain_on_extracted_frames_all_paths_agree(oracle, capi):
     m.close(); ex.close()
 
 
+def test_windowed_batch_with_different_capacities(oracle, capi):
+    """Batched problems whose two sets have different row pitches, window gate on: the reordered path against the oracle."""
+    torch = _torch()
+    st = torch.cuda.current_stream().cuda_stream
+    B, CAP1, CAP2 = 3, 384, 640
+    n1 = [384, 100, 257]; n2 = [640, 33, 500]
+    sets = [_sets(CAP1, CAP2, 500 + b) for b in range(B)]
+    D1 = torch.from_numpy(np.concatenate([s_[0] for s_ in sets])).cuda(); K1 = _dev_kp(torch, np.concatenate([s_[1] for s_ in sets]))
+    D2 = torch.from_numpy(np.concatenate([s_[2] for s_ in sets])).cuda(); K2 = _dev_kp(torch, np.concatenate([s_[3] for s_ in sets]))
+    N1 = torch.tensor(n1, dtype=torch.int32, device="cuda"); N2 = torch.tensor(n2, dtype=torch.int32, device="cuda")
+    out = torch.zeros(B * CAP1 * DM, dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(B, dtype=torch.int32, device="cuda")
+    m = capi.Matcher()
+    for mode in (3, 2, 1):
+        m.debug_set_window_mode(mode)
+        m.frame_match_batch_async(B, D1, K1, CAP1, N1, D2, K2, CAP2, N2, out, nout, 300.0, 70.0, 3, st)
+        torch.cuda.synchronize()
+        res = out.cpu().numpy().view(capi.DMATCH_DTYPE)
+        for b in range(B):
+            d1, k1, d2, k2 = sets[b]
+            ref = oracle.match_gated(d1[:n1[b]], k1[:n1[b]], d2[:n2[b]], k2[:n2[b]], 300.0, 70.0, 3)
+            assert int(nout[b].item()) == len(ref), (mode, b)
+            assert res[b * CAP1: b * CAP1 + len(ref)].tobytes() == ref.tobytes(), (mode, b)
+    m.close()
+
+
 def test_frame_match_async_and_batch(oracle, capi):
     torch = _torch()
     st = torch.cuda.current_stream().cuda_stream
